@@ -1,0 +1,171 @@
+"""The oracle (oracle/frad_oracle.py) against outputs of the reference itself.
+
+Fixtures under tests/golden/ were produced by oracle/gen_golden.py, which runs the reference
+from /root/reference in the build container.  Everything here is CPU-only."""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+from conftest import load_json, load_npz
+from oracle import frad_oracle as fo
+
+
+def _raw_to_pcm(raw, fmt, C):
+    dt = fo.pcm_dtype(fmt)
+    if raw.dtype == np.uint8 and dt.itemsize > 1:
+        raw = np.frombuffer(raw.tobytes(), dt)
+    return raw.reshape(-1, C), dt
+
+
+def test_g1_pack_unpack_bit_exact():
+    g1 = load_json("g1_pack.json")
+    x = np.array(g1["input"]).reshape(-1, 1)
+    assert len(g1["cases"]) == 36
+    for c in g1["cases"]:
+        frad, idx, ch, sr = fo.p4_analogue(x[:c["n"]], c["bits"], 48000, c["le"])
+        assert frad.hex() == c["hex"], c
+        assert idx == c["idx"]
+        dec = fo.p4_digital(frad, idx, 1, c["le"])
+        assert dec.astype("<f8").tobytes().hex() == c["decoded_hex"], c
+    # the survey's hand-captured vectors
+    assert fo.p4_analogue(x, 12, 48000, False)[0].hex() == "355b9a3c000a2e60"
+    assert fo.p4_analogue(x, 24, 48000, False)[0].hex() == "3eaaaabf35043f80003727c53dcccc"
+    assert fo.p4_analogue(x, 24, 48000, True)[0].hex() == "aaaa3e0435bf00803fc52737cccc3d"
+
+
+def test_g2_profile0_and_4_frames_bit_exact(g2):
+    arrs, index = g2
+    assert len(index) > 800
+    for c in index:
+        pcm, dt = _raw_to_pcm(arrs[c["key"] + "_in"], c["fmt"], c["C"])
+        frame = fo.to_f64(pcm, dt)
+        ana, dig = (fo.p0_analogue, fo.p0_digital) if c["profile"] == 0 else (fo.p4_analogue, fo.p4_digital)
+        frad, idx, ch, sr = ana(frame, c["bits"], 48000, c["le"])
+        assert idx == c["idx"] and ch == c["C"]
+        assert np.array_equal(np.frombuffer(frad, np.uint8), arrs[c["key"] + "_frad"]), c["key"]
+        dec = dig(frad, idx, ch, c["le"])
+        assert hashlib.sha256(dec.astype("<f8").tobytes()).hexdigest() == c["dec_sha256"], c["key"]
+        if c["dec"]:
+            assert np.array_equal(dec, arrs[c["key"] + "_dec"])
+
+
+def test_g2_payload_order_is_bin_major_channel_minor(g2):
+    arrs, index = g2
+    c = [c for c in index if c["key"].startswith("order")][0]
+    vals = np.frombuffer(arrs[c["key"] + "_frad"].tobytes(), ">f8") * 4
+    np.testing.assert_allclose(vals, [1, 1.5, 0, -0.7886, 0, 0, 0, -0.0560], atol=5e-4)
+
+
+def test_g3_streams_byte_for_byte():
+    g3 = load_json("g3_streams.json")
+    from frad_python_amd import synth
+    inputs = {
+        "cfg1": synth.sine(48000, 1, 48000, 440.0, 0.5).astype(">f8").tobytes(),
+        "tiny": np.array([0.25, -0.5, 0.75, 0.125]).astype(">f8").tobytes(),
+        "st": synth.to_pcm(synth.harmonic_mix(3000, 2, 44100, seed=3), "s16le").tobytes(),
+        "p1": load_npz("g3_p1_streams.npz")["p1_input_s16le"].tobytes(),
+    }
+    sizes = {}
+    for c in g3["cases"]:
+        kw = dict(c["params"])
+        pcm = inputs[c["name"].split("_")[0]]
+        out = fo.encode_stream(pcm, **kw)
+        sizes[c["name"]] = len(out)
+        assert len(out) == c["nbytes"], c["name"]
+        assert hashlib.sha256(out).hexdigest() == c["sha256"], c["name"]
+        if "stream_hex" in c:
+            assert out.hex() == c["stream_hex"]
+    # 24 frames x 32-byte header + payload for the 1 s mono sine
+    assert (sizes["cfg1_p0_b16"], sizes["cfg1_p0_b32"], sizes["cfg1_p0_b64"]) == (96768, 192768, 384768)
+
+
+def test_g3_profile1_stream_decodes_like_the_reference():
+    g3 = load_json("g3_streams.json")
+    arr = load_npz("g3_p1_streams.npz")
+    for lv in (0, 10, 20):
+        stream = arr[f"p1_lv{lv}_stream"].tobytes()
+        want = arr[f"p1_lv{lv}_decoded"]
+        got = fo.decode_stream(stream)
+        assert got.shape == want.shape
+        assert np.array_equal(got, want)
+
+
+def test_g4_profile1_pre_entropy_bit_exact(g4):
+    frames = g4["frames_s16le"]
+    dt = fo.pcm_dtype("s16le")
+    for lv in (0, 10, 20):
+        ll = 1.25 ** lv / 19.0 + 0.5
+        for i, fr in enumerate(frames):
+            q, tq, aux = fo.p1_analogue_pre(fo.to_f64(fr, dt), 16, 48000, ll)
+            wq, wtq = g4[f"lv{lv}_f{i}_q"], g4[f"lv{lv}_f{i}_tq"]
+            # the reference's Golomb decoder drops a trailing run of zeros; compare the prefix
+            assert np.array_equal(q[:len(wq)], wq) and not q[len(wq):].any()
+            assert np.array_equal(tq[:len(wtq)], wtq) and not tq[len(wtq):].any()
+            frad = fo.p1_pack(q, tq)
+            assert np.array_equal(np.frombuffer(frad, np.uint8), g4[f"lv{lv}_f{i}_frad"])
+            dec = fo.p1_digital(frad, 2, 2, 48000, 2048)
+            assert np.array_equal(dec, g4[f"lv{lv}_f{i}_dec"])
+            if lv == 20:
+                assert np.array_equal(aux["thres"], g4[f"lv{lv}_f{i}_thres"])
+                div = np.array([fo.spread_thresholds(aux["thres"][c], 2048, 48000) for c in range(2)])
+                assert np.array_equal(div, g4[f"lv{lv}_f{i}_div"])
+
+
+def test_g4_other_rates_and_sizes(g4):
+    dt = fo.pcm_dtype("s16le")
+    for N, sr in ((512, 44100), (2048, 96000), (1024, 8000), (640, 32000)):
+        x = fo.to_f64(g4[f"alt_{N}_{sr}_in"], dt)
+        q, tq, aux = fo.p1_analogue_pre(x, 16, sr, 1.0)
+        wq, wtq = g4[f"alt_{N}_{sr}_q"], g4[f"alt_{N}_{sr}_tq"]
+        assert np.array_equal(q[:len(wq)], wq) and not q[len(wq):].any()
+        assert np.array_equal(tq[:len(wtq)], wtq) and not tq[len(wtq):].any()
+        assert fo.band_edges(N, sr) == list(g4[f"alt_{N}_{sr}_edges"])
+        dec = fo.p1_digital(fo.p1_pack(q, tq), 2, 1, sr, N)
+        assert np.array_equal(dec, g4[f"alt_{N}_{sr}_dec"])
+    # 48 kHz N=2048 band edges
+    assert fo.band_edges(2048, 48000)[:23] == [0, 17, 34, 51, 68, 85, 102, 119, 137, 171, 205, 239, 273, 341,
+                                               410, 478, 580, 683, 819, 1024, 1331, 1707, 2048]
+
+
+def test_g4_golomb_known_answers(g4):
+    for c in load_json("g4_golomb.json"):
+        a = np.array(c["data"], dtype=int)
+        assert fo.golomb_encode(a).hex() == c["hex"], c
+        back = fo.golomb_decode(bytes.fromhex(c["hex"]))
+        n = len(back)
+        assert np.array_equal(back, a[:n]) and not a[n:].any()
+    assert np.array_equal(fo.hanning_in_overlap(128), g4["hann_128"])
+
+
+def test_g5_edges(g5):
+    xn = g5["nan_in"]
+    for bits in (16, 32, 64):
+        frad, idx, ch, sr = fo.p4_analogue(xn, bits, 48000, False)
+        assert np.array_equal(np.frombuffer(frad, np.uint8), g5[f"nan_p4_b{bits}_frad"])
+        assert np.array_equal(fo.p4_digital(frad, idx, 1, False), g5[f"nan_p4_b{bits}_dec"])
+    pay = g5["scrub_payload"].tobytes()
+    assert np.array_equal(fo.p4_digital(pay, 3, 1, False), g5["scrub_p4_dec"])
+    assert np.array_equal(fo.p0_digital(pay, 3, 1, False), g5["scrub_p0_dec"])
+    assert np.array_equal(fo.p0_digital(pay, 3, 2, False), g5["scrub_p0_dec_c2"])
+    for name, bits in (("esc16", 16), ("esc32", 32), ("esc12", 12), ("esc24", 24)):
+        xe = g5[f"{name}_in"]
+        for prof, ana in ((0, fo.p0_analogue), (4, fo.p4_analogue)):
+            frad, idx, ch, sr = ana(xe, bits, 48000, False)
+            assert idx == int(g5[f"{name}_p{prof}_idx"]), (name, prof)
+            assert np.array_equal(np.frombuffer(frad, np.uint8), g5[f"{name}_p{prof}_frad"])
+    assert int(g5["esc16_p0_idx"]) == 2          # 1e6 at 16 bit -> 24 bit
+    with pytest.raises(OverflowError):
+        fo.p4_analogue(np.array([[np.inf]]), 16, 48000, False)
+    rb = g5["fmt_bytes"].tobytes()
+    for fmt in fo.PCM_FORMATS:
+        dt = fo.pcm_dtype(fmt)
+        conv = np.asarray(fo.to_f64(np.frombuffer(rb, dt), dt))
+        want = g5[f"to_f64_{fmt}"]
+        assert conv.dtype.kind + str(conv.dtype.itemsize) == str(g5[f"to_f64_{fmt}_kind"])[1:]
+        assert np.array_equal(conv.astype(want.dtype), want, equal_nan=True), fmt
+    ff = g5["from_f64_in"]
+    for fmt in ("s16le", "s32le", "u8", "u16le", "s8"):
+        with np.errstate(all="ignore"):
+            assert np.array_equal(fo.from_f64(ff, fo.pcm_dtype(fmt)), g5[f"from_f64_{fmt}"]), fmt
