@@ -1,0 +1,109 @@
+"""ctypes binding of the C-ABI in include/frad_hip.h (libfrad_hip.so).
+
+PyTorch is plumbing here (device memory + streams): the signatures carry raw device pointers
+and sizes only.  There is no CPU fallback: if the HIP library has not been built, or no MI355X
+is visible, every operator raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfrad_hip.so")
+
+FRAD_LITTLE_ENDIAN = 1
+FRAD_RAW_BE_INTS = 2
+
+# every symbol include/frad_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "frad_abi_version": (c_int, []),
+    "frad_strerror": (c_char_p, [c_int]),
+    "frad_last_hip_error": (c_int, []),
+    "frad_payload_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "frad_has_fast_path": (c_int, [c_int32, c_int32, c_int32]),
+    "frad_plan_prepare": (c_int, [c_int32, c_int32]),
+    "frad_plan_clear": (None, []),
+    "frad_p0_analogue": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_int32, c_int64, c_int32, c_uint32,
+                                 c_void_p, c_int64, c_void_p, c_void_p]),
+    "frad_p0_digital": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_uint32, c_void_p, c_void_p]),
+    "frad_p4_analogue": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_int32, c_int64, c_int32, c_uint32,
+                                 c_void_p, c_int64, c_void_p, c_void_p]),
+    "frad_p4_digital": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_uint32, c_void_p, c_void_p]),
+    "frad_p1_analogue": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_int32, c_int64, c_int32, c_int32, c_int32,
+                                 c_double, c_uint32, c_void_p, c_void_p, c_void_p]),
+    "frad_p1_digital": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "frad_p1_overlap_add": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+
+class FradError(RuntimeError):
+    def __init__(self, status: int, message: str, hip_error: int = 0):
+        super().__init__(f"libfrad_hip: {message} (status {status}" + (f", hipError {hip_error})" if hip_error else ")"))
+        self.status = status
+        self.hip_error = hip_error
+
+
+class FradLib:
+    """One loaded copy of the C-ABI library; methods take raw pointers (ints) and sizes."""
+
+    def __init__(self, path: str = LIB_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: the HIP transform core has not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback for the product path.")
+        self.path = path
+        self.dll = ctypes.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(self.dll, name)           # AttributeError if the library lacks a symbol
+            fn.restype, fn.argtypes = res, args
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise FradError(rc, self.dll.frad_strerror(rc).decode(), self.dll.frad_last_hip_error())
+
+    def payload_bytes(self, N, C, bits):
+        return int(self.dll.frad_payload_bytes(N, C, bits))
+
+    def has_fast_path(self, N, C, f32=False):
+        return bool(self.dll.frad_has_fast_path(N, C, int(f32)))
+
+    def plan_prepare(self, N, f32=False):
+        self._check(self.dll.frad_plan_prepare(N, int(f32)))
+
+    def p0_analogue(self, pcm, dtype, n_frames, N, C, frame_stride, bits, flags, payload, payload_stride, absmax, stream=0):
+        self._check(self.dll.frad_p0_analogue(pcm, dtype, n_frames, N, C, frame_stride, bits, flags, payload,
+                                               payload_stride, absmax, stream))
+
+    def p0_digital(self, payload, payload_stride, n_frames, N, C, bits, flags, out, stream=0):
+        self._check(self.dll.frad_p0_digital(payload, payload_stride, n_frames, N, C, bits, flags, out, stream))
+
+    def p4_analogue(self, pcm, dtype, n_frames, N, C, frame_stride, bits, flags, payload, payload_stride, absmax, stream=0):
+        self._check(self.dll.frad_p4_analogue(pcm, dtype, n_frames, N, C, frame_stride, bits, flags, payload,
+                                               payload_stride, absmax, stream))
+
+    def p4_digital(self, payload, payload_stride, n_frames, N, C, bits, flags, out, stream=0):
+        self._check(self.dll.frad_p4_digital(payload, payload_stride, n_frames, N, C, bits, flags, out, stream))
+
+    def p1_analogue(self, pcm, dtype, n_frames, N, C, frame_stride, n_valid, bits, srate, loss_level, flags, q, tq, stream=0):
+        self._check(self.dll.frad_p1_analogue(pcm, dtype, n_frames, N, C, frame_stride, n_valid, bits, srate,
+                                               loss_level, flags, q, tq, stream))
+
+    def p1_digital(self, q, tq, n_frames, N, C, bits, srate, out, stream=0):
+        self._check(self.dll.frad_p1_digital(q, tq, n_frames, N, C, bits, srate, out, stream))
+
+    def p1_overlap_add(self, frames, n_frames, N, C, ratio, prev_tail, out, next_tail, stream=0):
+        self._check(self.dll.frad_p1_overlap_add(frames, n_frames, N, C, ratio, prev_tail, out, next_tail, stream))
+
+
+_lib: FradLib | None = None
+
+
+def load() -> FradLib:
+    """The product library (HIP, gfx950).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        _lib = FradLib(LIB_PATH)
+    return _lib

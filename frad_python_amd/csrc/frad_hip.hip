@@ -1,0 +1,394 @@
+// frad_hip.hip -- C-ABI entry points of libfrad_hip.so (see include/frad_hip.h) and kernel launch
+// logic.  Built with  hipcc --offload-arch=gfx950 -shared -fPIC  (see __graft_entry__.build()).
+#include "frad_kernels.hpp"
+#include "../../include/frad_hip.h"
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+using namespace frad;
+
+namespace {
+
+thread_local int g_last_hip = 0;
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_last_hip = (int)e_; return FRAD_E_HIP; } } while (0)
+
+constexpr int kLdsBytes = 160 * 1024;     // CDNA4: 160 KiB LDS per CU, one workgroup may own it all
+
+bool valid_bits(int b) { return b == 12 || b == 16 || b == 24 || b == 32 || b == 48 || b == 64; }
+bool valid_dtype(int d) {
+    if (d < 0 || d > 23) return false;
+    const int kind = d >> 3, lg = (d >> 1) & 3, be = d & 1;
+    if (kind == 2 && lg == 0) return false;
+    if (lg == 0 && be) return false;
+    return true;
+}
+int log2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
+int gcd(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// exp(-i * pi * p / q) for even q, exact at the multiples of pi/2 and symmetric inside octants.
+void unit_neg(long long p, long long q, long double& re, long double& im) {
+    const long double PI = 3.14159265358979323846264338327950288419716939937510L;
+    long long r = p % (2 * q); if (r < 0) r += 2 * q;
+    const long long h = q / 2;                 // q is even
+    const int quad = (int)(r / h);
+    const long long rem = r % h;
+    long double c, s;
+    if (4 * rem <= q) { c = cosl(PI * (long double)rem / (long double)q); s = sinl(PI * (long double)rem / (long double)q); }
+    else { c = sinl(PI * (long double)(h - rem) / (long double)q); s = cosl(PI * (long double)(h - rem) / (long double)q); }
+    if (rem == 0) { c = 1.0L; s = 0.0L; }
+    long double C, S;
+    switch (quad) { case 0: C = c; S = s; break; case 1: C = -s; S = c; break; case 2: C = -c; S = -s; break; default: C = s; S = -c; }
+    re = C; im = -S;
+}
+
+struct Tables { void* tw = nullptr; void* post = nullptr; };
+struct DirectTable { double* ct = nullptr; };
+
+std::mutex g_mu;
+std::map<std::tuple<int, int, int>, Tables> g_tables;        // (device, log2M, f32)
+std::map<std::pair<int, int>, DirectTable> g_direct;         // (device, N)
+
+template <typename T>
+int build_tables(int log2m, Tables& out) {
+    const int M = 1 << log2m, N = 2 * M;
+    std::vector<cx<T>> tw(M), post(2 * (M / 2 + 1));
+    for (int k = 0; k < M; ++k) {
+        long double re, im; unit_neg(2LL * k, M, re, im);
+        tw[k].x = (T)re; tw[k].y = (T)im;
+    }
+    for (int k = 0; k <= M / 2; ++k) {
+        long double re, im;
+        unit_neg(k, 2LL * N, re, im);              // w_k = exp(-i pi k / 2N)
+        post[2 * k].x = (T)re; post[2 * k].y = (T)im;
+        unit_neg((long long)N + 5LL * k, 2LL * N, re, im);   // g_k = exp(-i pi (1/2 + 5k/2N))
+        post[2 * k + 1].x = (T)re; post[2 * k + 1].y = (T)im;
+    }
+    HIPCHK(hipMalloc(&out.tw, tw.size() * sizeof(cx<T>)));
+    HIPCHK(hipMalloc(&out.post, post.size() * sizeof(cx<T>)));
+    HIPCHK(hipMemcpy(out.tw, tw.data(), tw.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(out.post, post.data(), post.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
+    return FRAD_OK;
+}
+
+int get_tables(int log2m, bool f32, Tables& out) {
+    int dev = 0; HIPCHK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_tuple(dev, log2m, (int)f32);
+    auto it = g_tables.find(key);
+    if (it != g_tables.end()) { out = it->second; return FRAD_OK; }
+    Tables t;
+    const int rc = f32 ? build_tables<float>(log2m, t) : build_tables<double>(log2m, t);
+    if (rc != FRAD_OK) return rc;
+    g_tables[key] = t; out = t;
+    return FRAD_OK;
+}
+
+int get_direct(int N, DirectTable& out) {
+    int dev = 0; HIPCHK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_pair(dev, N);
+    auto it = g_direct.find(key);
+    if (it != g_direct.end()) { out = it->second; return FRAD_OK; }
+    if (g_direct.size() >= 64) {                       // bounded cache of odd frame lengths
+        for (auto& kv : g_direct) (void)hipFree(kv.second.ct);
+        g_direct.clear();
+    }
+    std::vector<double> ct(4 * (size_t)N);
+    for (long long j = 0; j < 4LL * N; ++j) { long double re, im; unit_neg(j, 2LL * N, re, im); ct[j] = (double)re; }
+    DirectTable t;
+    HIPCHK(hipMalloc(&t.ct, ct.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(t.ct, ct.data(), ct.size() * sizeof(double), hipMemcpyHostToDevice));
+    g_direct[key] = t; out = t;
+    return FRAD_OK;
+}
+
+// launch geometry of the FFT kernels
+struct FastCfg { bool ok = false; int log2m = 0, team = 0, fpb = 0, threads = 0; size_t lds = 0; };
+int team_of(int log2m) {
+    switch (log2m) { case 6: return 16; case 7: return 32; case 8: case 9: case 10: return 64;
+                     case 11: return 128; case 12: return 256; case 13: return 512; default: return 0; }
+}
+FastCfg fast_cfg(int N, int C, bool f32) {
+    FastCfg c;
+    const int l2 = log2_exact(N);
+    if (l2 < 7 || l2 > 14 || C < 1) return c;
+    c.log2m = l2 - 1; c.team = team_of(c.log2m);
+    const int M = 1 << c.log2m;
+    const size_t per_cf = (size_t)padded_slots(M) * (f32 ? 8 : 16);
+    const long long pft = (long long)C * c.team;
+    const size_t pfl = per_cf * (size_t)C;
+    int q = 1;
+    if (c.team < 64) { const int w = 64 / c.team; q = w / gcd(C, w); }
+    if (q * pft > 1024 || q * pfl > (size_t)kLdsBytes) return c;
+    int fpb = q;
+    while ((fpb + q) * pft <= 512 && (size_t)(fpb + q) * pfl <= 80 * 1024) fpb += q;
+    c.fpb = fpb; c.threads = (int)(fpb * pft); c.lds = fpb * pfl; c.ok = true;
+    return c;
+}
+
+template <typename K> void allow_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+int check_common(const void* a, const void* b, long long n_frames, int N, int C, int bits) {
+    if (n_frames < 0 || N < 1 || C < 1 || C > 256 || !valid_bits(bits)) return FRAD_E_INVALID;
+    if (n_frames > 0 && (a == nullptr || b == nullptr)) return FRAD_E_INVALID;
+    if ((long long)N * C > (1LL << 30)) return FRAD_E_UNSUPPORTED;
+    return FRAD_OK;
+}
+
+int blocks_per_frame(long long work_items) {
+    long long b = (work_items + 255) / 256;
+    return (int)(b < 1 ? 1 : b > 64 ? 64 : b);
+}
+
+// ---- kernel selection by template expansion -------------------------------------------------
+template <int BITS>
+int launch_p4_pack_lg(int lg, dim3 grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* am, const Geom& g, int bpf) {
+    switch (lg) {
+        case 0: hipLaunchKernelGGL((k_p4_pack<BITS, 0>), grid, dim3(256), 0, s, pcm, pay, am, g, bpf); break;
+        case 1: hipLaunchKernelGGL((k_p4_pack<BITS, 1>), grid, dim3(256), 0, s, pcm, pay, am, g, bpf); break;
+        case 2: hipLaunchKernelGGL((k_p4_pack<BITS, 2>), grid, dim3(256), 0, s, pcm, pay, am, g, bpf); break;
+        default: hipLaunchKernelGGL((k_p4_pack<BITS, 3>), grid, dim3(256), 0, s, pcm, pay, am, g, bpf); break;
+    }
+    return FRAD_OK;
+}
+
+template <typename T, int LOG2M>
+int launch_fwd_lg(int lg, const FastCfg& c, dim3 grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* am,
+                  const Tables& tb, const Geom& g, int ai, int ao) {
+    const cx<T>* tw = static_cast<const cx<T>*>(tb.tw); const cx<T>* post = static_cast<const cx<T>*>(tb.post);
+#define FRAD_FWD(LGV) do { allow_lds(k_p0_fwd<T, LOG2M, LGV>, c.lds); \
+        hipLaunchKernelGGL((k_p0_fwd<T, LOG2M, LGV>), grid, dim3(c.threads), c.lds, s, pcm, pay, am, tw, post, g, ai, ao); } while (0)
+    if constexpr (sizeof(T) == 4) {
+        if (lg == 1) FRAD_FWD(1); else FRAD_FWD(2);
+    } else {
+        switch (lg) { case 0: FRAD_FWD(0); break; case 1: FRAD_FWD(1); break; case 2: FRAD_FWD(2); break; default: FRAD_FWD(3); break; }
+    }
+#undef FRAD_FWD
+    return FRAD_OK;
+}
+
+template <typename T>
+int launch_fwd(int lg, const FastCfg& c, dim3 grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* am,
+               const Tables& tb, const Geom& g, int ai, int ao) {
+    switch (c.log2m) {
+        case 6: return launch_fwd_lg<T, 6>(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao);
+        case 7: return launch_fwd_lg<T, 7>(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao);
+        case 8: return launch_fwd_lg<T, 8>(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao);
+        case 9: return launch_fwd_lg<T, 9>(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao);
+        case 10: return launch_fwd_lg<T, 10>(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao);
+        case 11: return launch_fwd_lg<T, 11>(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao);
+        case 12: return launch_fwd_lg<T, 12>(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao);
+        default: return launch_fwd_lg<T, 13>(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao);
+    }
+}
+
+int launch_inv(const FastCfg& c, dim3 grid, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb, const Geom& g, int ai) {
+    const cx<double>* tw = static_cast<const cx<double>*>(tb.tw); const cx<double>* post = static_cast<const cx<double>*>(tb.post);
+#define FRAD_INV(L) case L: allow_lds(k_p0_inv<L>, c.lds); hipLaunchKernelGGL((k_p0_inv<L>), grid, dim3(c.threads), c.lds, s, pay, out, tw, post, g, ai); break
+    switch (c.log2m) { FRAD_INV(6); FRAD_INV(7); FRAD_INV(8); FRAD_INV(9); FRAD_INV(10); FRAD_INV(11); FRAD_INV(12); FRAD_INV(13); default: return FRAD_E_UNSUPPORTED; }
+#undef FRAD_INV
+    return FRAD_OK;
+}
+
+Geom make_geom(long long n_frames, int N, int C, long long frame_stride, long long payload_stride, int bits, uint32_t flags, int dtype) {
+    Geom g{};
+    g.n_frames = n_frames; g.frame_stride = frame_stride; g.payload_stride = payload_stride;
+    g.N = N; g.C = C; g.bits = bits; g.le = (flags & FRAD_LITTLE_ENDIAN) ? 1 : 0; g.dtype = dtype;
+    g.raw_be = (flags & FRAD_RAW_BE_INTS) ? 1 : 0; g.fpb = 1; g.n_valid = N;
+    return g;
+}
+
+bool input_aligned(const void* pcm, long long frame_stride, int N, int C, int lg) {
+    return aligned16(pcm) && (((frame_stride * C) << lg) % 16 == 0) && ((((long long)N * C) << lg) % 16 == 0);
+}
+
+}  // namespace
+
+extern "C" {
+
+int frad_abi_version(void) { return FRAD_ABI_VERSION; }
+int frad_last_hip_error(void) { return g_last_hip; }
+
+const char* frad_strerror(int status) {
+    switch (status) {
+        case FRAD_OK: return "ok";
+        case FRAD_E_INVALID: return "invalid argument";
+        case FRAD_E_UNSUPPORTED: return "geometry not supported by the HIP transform core (frame too large for LDS, or profile-1 float input)";
+        case FRAD_E_HIP: return "HIP runtime error (no MI355X visible, or a launch failed); see frad_last_hip_error()";
+        case FRAD_E_NOMEM: return "out of device memory";
+        default: return "unknown frad_status";
+    }
+}
+
+size_t frad_payload_bytes(int32_t N, int32_t C, int32_t bits) {
+    const size_t n = (size_t)N * (size_t)C;
+    return bits == 12 ? (n * 3 + 1) / 2 : n * (size_t)bits / 8;
+}
+
+int frad_has_fast_path(int32_t N, int32_t C, int32_t compute_f32) { return fast_cfg(N, C, compute_f32 != 0).ok ? 1 : 0; }
+
+int frad_plan_prepare(int32_t N, int32_t compute_f32) {
+    const int l2 = log2_exact(N);
+    if (l2 >= 7 && l2 <= 14) { Tables t; return get_tables(l2 - 1, compute_f32 != 0, t); }
+    if (N < 1) return FRAD_E_INVALID;
+    DirectTable d; return get_direct(N, d);
+}
+
+void frad_plan_clear(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_tables) { (void)hipFree(kv.second.tw); (void)hipFree(kv.second.post); }
+    for (auto& kv : g_direct) (void)hipFree(kv.second.ct);
+    g_tables.clear(); g_direct.clear();
+}
+
+int frad_p4_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C, int64_t frame_stride,
+                     int32_t bits, uint32_t flags, void* payload, int64_t payload_stride, double* absmax, void* stream) {
+    int rc = check_common(pcm, payload, n_frames, N, C, bits);
+    if (rc != FRAD_OK) return rc;
+    if (!valid_dtype(pcm_dtype) || payload_stride < (int64_t)frad_payload_bytes(N, C, bits)) return FRAD_E_INVALID;
+    if (n_frames == 0) return FRAD_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (absmax) HIPCHK(hipMemsetAsync(absmax, 0, sizeof(double) * (size_t)n_frames, s));
+    const int lg = (pcm_dtype >> 1) & 3;
+    Geom g = make_geom(n_frames, N, C, frame_stride, payload_stride, bits, flags, pcm_dtype);
+    const long long NC = (long long)N * C;
+    const int U = unit_values(bits);
+    const bool fast = NC >= U && aligned16(pcm) && ((frame_stride * C) << lg) % 16 == 0 && aligned16(payload) && payload_stride % 16 == 0;
+    const int bpf = blocks_per_frame(fast ? NC / U : NC);
+    if (n_frames * bpf > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
+    dim3 grid((unsigned)(n_frames * bpf));
+    const unsigned char* in = static_cast<const unsigned char*>(pcm);
+    unsigned char* out = static_cast<unsigned char*>(payload);
+    if (fast) {
+        switch (bits) {
+            case 12: launch_p4_pack_lg<12>(lg, grid, s, in, out, absmax, g, bpf); break;
+            case 16: launch_p4_pack_lg<16>(lg, grid, s, in, out, absmax, g, bpf); break;
+            case 24: launch_p4_pack_lg<24>(lg, grid, s, in, out, absmax, g, bpf); break;
+            case 32: launch_p4_pack_lg<32>(lg, grid, s, in, out, absmax, g, bpf); break;
+            case 48: launch_p4_pack_lg<48>(lg, grid, s, in, out, absmax, g, bpf); break;
+            default: launch_p4_pack_lg<64>(lg, grid, s, in, out, absmax, g, bpf); break;
+        }
+    } else {
+        hipLaunchKernelGGL(k_p4_pack_slow, grid, dim3(256), 0, s, in, out, absmax, g, bpf);
+    }
+    HIPCHK(hipGetLastError());
+    return FRAD_OK;
+}
+
+int frad_p4_digital(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C, int32_t bits,
+                    uint32_t flags, double* pcm_out, void* stream) {
+    int rc = check_common(payload, pcm_out, n_frames, N, C, bits);
+    if (rc != FRAD_OK) return rc;
+    if (payload_stride < (int64_t)frad_payload_bytes(N, C, bits)) return FRAD_E_INVALID;
+    if (n_frames == 0) return FRAD_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Geom g = make_geom(n_frames, N, C, N, payload_stride, bits, flags, FRAD_PCM_F64LE);
+    const long long NC = (long long)N * C;
+    const int U = unit_values(bits);
+    const bool fast = NC >= U && aligned16(payload) && payload_stride % 16 == 0 && aligned16(pcm_out) && (NC % 2 == 0);
+    const int bpf = blocks_per_frame(fast ? NC / U : NC);
+    if (n_frames * bpf > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
+    dim3 grid((unsigned)(n_frames * bpf));
+    const unsigned char* in = static_cast<const unsigned char*>(payload);
+    if (fast) {
+        switch (bits) {
+            case 12: hipLaunchKernelGGL(k_p4_unpack<12>, grid, dim3(256), 0, s, in, pcm_out, g, bpf); break;
+            case 16: hipLaunchKernelGGL(k_p4_unpack<16>, grid, dim3(256), 0, s, in, pcm_out, g, bpf); break;
+            case 24: hipLaunchKernelGGL(k_p4_unpack<24>, grid, dim3(256), 0, s, in, pcm_out, g, bpf); break;
+            case 32: hipLaunchKernelGGL(k_p4_unpack<32>, grid, dim3(256), 0, s, in, pcm_out, g, bpf); break;
+            case 48: hipLaunchKernelGGL(k_p4_unpack<48>, grid, dim3(256), 0, s, in, pcm_out, g, bpf); break;
+            default: hipLaunchKernelGGL(k_p4_unpack<64>, grid, dim3(256), 0, s, in, pcm_out, g, bpf); break;
+        }
+    } else {
+        hipLaunchKernelGGL(k_p4_unpack_slow, grid, dim3(256), 0, s, in, pcm_out, g, bpf);
+    }
+    HIPCHK(hipGetLastError());
+    return FRAD_OK;
+}
+
+int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C, int64_t frame_stride,
+                     int32_t bits, uint32_t flags, void* payload, int64_t payload_stride, double* absmax, void* stream) {
+    int rc = check_common(pcm, payload, n_frames, N, C, bits);
+    if (rc != FRAD_OK) return rc;
+    if (!valid_dtype(pcm_dtype) || payload_stride < (int64_t)frad_payload_bytes(N, C, bits)) return FRAD_E_INVALID;
+    if (n_frames == 0) return FRAD_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int lg = (pcm_dtype >> 1) & 3;
+    const bool f32 = (pcm_dtype >> 3) == 2 && lg <= 2;
+    Geom g = make_geom(n_frames, N, C, frame_stride, payload_stride, bits, flags, pcm_dtype);
+    const int ai = input_aligned(pcm, frame_stride, N, C, lg) ? 1 : 0;
+    const int ao = (aligned16(payload) && payload_stride % 16 == 0) ? 1 : 0;
+    const unsigned char* in = static_cast<const unsigned char*>(pcm);
+    unsigned char* out = static_cast<unsigned char*>(payload);
+    const FastCfg c = fast_cfg(N, C, f32);
+    if (c.ok) {
+        Tables tb; rc = get_tables(c.log2m, f32, tb);
+        if (rc != FRAD_OK) return rc;
+        if (absmax) HIPCHK(hipMemsetAsync(absmax, 0, sizeof(double) * (size_t)n_frames, s));
+        g.fpb = c.fpb;
+        dim3 grid((unsigned)((n_frames + c.fpb - 1) / c.fpb));
+        rc = f32 ? launch_fwd<float>(lg, c, grid, s, in, out, absmax, tb, g, ai, ao)
+                 : launch_fwd<double>(lg, c, grid, s, in, out, absmax, tb, g, ai, ao);
+        if (rc != FRAD_OK) return rc;
+    } else {
+        const size_t lds = 2 * (size_t)N * C * (f32 ? 4 : 8);
+        if (lds > (size_t)kLdsBytes || n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
+        DirectTable d; rc = get_direct(N, d);
+        if (rc != FRAD_OK) return rc;
+        if (absmax) HIPCHK(hipMemsetAsync(absmax, 0, sizeof(double) * (size_t)n_frames, s));
+        dim3 grid((unsigned)n_frames);
+#define FRAD_DIR(TT, LGV) do { allow_lds(k_p0_fwd_direct<TT, LGV>, lds); \
+        hipLaunchKernelGGL((k_p0_fwd_direct<TT, LGV>), grid, dim3(256), lds, s, in, out, absmax, d.ct, g, ai, ao); } while (0)
+        if (f32) { if (lg == 1) FRAD_DIR(float, 1); else FRAD_DIR(float, 2); }
+        else switch (lg) { case 0: FRAD_DIR(double, 0); break; case 1: FRAD_DIR(double, 1); break; case 2: FRAD_DIR(double, 2); break; default: FRAD_DIR(double, 3); break; }
+#undef FRAD_DIR
+    }
+    HIPCHK(hipGetLastError());
+    return FRAD_OK;
+}
+
+int frad_p0_digital(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C, int32_t bits,
+                    uint32_t flags, double* pcm_out, void* stream) {
+    int rc = check_common(payload, pcm_out, n_frames, N, C, bits);
+    if (rc != FRAD_OK) return rc;
+    if (payload_stride < (int64_t)frad_payload_bytes(N, C, bits)) return FRAD_E_INVALID;
+    if (n_frames == 0) return FRAD_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Geom g = make_geom(n_frames, N, C, N, payload_stride, bits, flags, FRAD_PCM_F64LE);
+    const int ai = (aligned16(payload) && payload_stride % 16 == 0) ? 1 : 0;
+    const unsigned char* in = static_cast<const unsigned char*>(payload);
+    const FastCfg c = fast_cfg(N, C, false);
+    if (c.ok) {
+        Tables tb; rc = get_tables(c.log2m, false, tb);
+        if (rc != FRAD_OK) return rc;
+        g.fpb = c.fpb;
+        dim3 grid((unsigned)((n_frames + c.fpb - 1) / c.fpb));
+        rc = launch_inv(c, grid, s, in, pcm_out, tb, g, ai);
+        if (rc != FRAD_OK) return rc;
+    } else {
+        const size_t lds = 2 * (size_t)N * C * 8;
+        if (lds > (size_t)kLdsBytes || n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
+        DirectTable d; rc = get_direct(N, d);
+        if (rc != FRAD_OK) return rc;
+        allow_lds(k_p0_inv_direct, lds);
+        hipLaunchKernelGGL(k_p0_inv_direct, dim3((unsigned)n_frames), dim3(256), lds, s, in, pcm_out, d.ct, g, ai);
+    }
+    HIPCHK(hipGetLastError());
+    return FRAD_OK;
+}
+
+int frad_p1_analogue(const void*, int32_t, int64_t, int32_t, int32_t, int64_t, int32_t, int32_t, int32_t, double,
+                     uint32_t, int32_t*, int32_t*, void*) { return FRAD_E_UNSUPPORTED; }
+int frad_p1_digital(const int32_t*, const int32_t*, int64_t, int32_t, int32_t, int32_t, int32_t, double*, void*) { return FRAD_E_UNSUPPORTED; }
+int frad_p1_overlap_add(const double*, int64_t, int32_t, int32_t, int32_t, const double*, double*, double*, void*) { return FRAD_E_UNSUPPORTED; }
+
+}  // extern "C"

@@ -1,0 +1,17 @@
+// frad_platform.hpp -- the one seam between the kernels and the toolchain.
+//
+// Product build (hipcc --offload-arch=gfx950): the real HIP runtime.  The kernels are written for
+// gfx950 only: wave64, LDS, no portability layer.
+// Test build (g++ -DFRAD_HOST_EMULATION, tests/emu/): the same kernel source runs under a small
+// thread-per-lane interpreter so that indexing and packing logic can be checked -- and run under
+// AddressSanitizer, which the GPU pool does not offer -- in the CPU-only build container.  The
+// emulator is test infrastructure and is never linked into libfrad_hip.so.
+#pragma once
+#ifdef FRAD_HOST_EMULATION
+#include "hip_emu.hpp"
+#else
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#define FRAD_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+#include <stdint.h>

@@ -1,0 +1,128 @@
+/*
+ * frad_hip.h -- C-ABI of the MI355X-native FrAD transform core (libfrad_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of H4n-uL/FrAD_Python: the per-frame Fourier
+ * analysis/synthesis + quantise + bit-depth pack/unpack that the reference reaches only through
+ * the two `match` dispatches
+ *      src/libfrad/encoder.py:96-100   fourier.profileN.analogue(frame, bits, srate, endian|loss_level)
+ *      src/libfrad/decoder.py:70-74    fourier.profileN.digital(frad, depth_idx, channels, ...)
+ * Each entry point below replaces one of those Python functions with ONE batched launch over
+ * `n_frames` independent frames of identical geometry.  The reference has no FFI of its own
+ * (it is pure Python); INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) owned by the caller; nothing is allocated per call
+ *    except the immutable twiddle tables, created once per (N, precision) -- call
+ *    frad_plan_prepare() first if the launch must be hipGraph-capturable;
+ *  - all work is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *  - return value: FRAD_OK (0) or a negative frad_status; never exit(), never throws;
+ *  - "sample-frame" = one sample of every channel; PCM is interleaved [n, C] exactly as the
+ *    reference reshapes it (encoder.py:84);
+ *  - there is NO CPU fallback: without a HIP device every launch returns FRAD_E_HIP.
+ */
+#ifndef FRAD_HIP_H
+#define FRAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRAD_ABI_VERSION 1
+
+typedef enum frad_status {
+    FRAD_OK = 0,
+    FRAD_E_INVALID = -1,      /* bad argument (null pointer, illegal depth, N or C out of range)   */
+    FRAD_E_UNSUPPORTED = -2,  /* legal in the reference but not built here yet (see strerror)      */
+    FRAD_E_HIP = -3,          /* a HIP runtime call failed; frad_last_hip_error() has the code     */
+    FRAD_E_NOMEM = -4
+} frad_status;
+
+/* PCM element type: kind*8 + log2(itemsize)*2 + big_endian, kind 0 = unsigned int, 1 = signed
+ * int, 2 = IEEE float.  Replaces ff_format_to_numpy_type (src/libfrad/backend/pcmformat.py:4-32). */
+#define FRAD_PCM_CODE(kind, log2size, be) ((kind) * 8 + (log2size) * 2 + (be))
+enum {
+    FRAD_PCM_U8 = 0, FRAD_PCM_U16LE = 2, FRAD_PCM_U16BE = 3, FRAD_PCM_U32LE = 4, FRAD_PCM_U32BE = 5,
+    FRAD_PCM_U64LE = 6, FRAD_PCM_U64BE = 7,
+    FRAD_PCM_S8 = 8, FRAD_PCM_S16LE = 10, FRAD_PCM_S16BE = 11, FRAD_PCM_S32LE = 12, FRAD_PCM_S32BE = 13,
+    FRAD_PCM_S64LE = 14, FRAD_PCM_S64BE = 15,
+    FRAD_PCM_F16LE = 18, FRAD_PCM_F16BE = 19, FRAD_PCM_F32LE = 20, FRAD_PCM_F32BE = 21,
+    FRAD_PCM_F64LE = 22, FRAD_PCM_F64BE = 23
+};
+
+/* flags */
+#define FRAD_LITTLE_ENDIAN 1u /* payload endianness (ASFH `endian`, tools/asfh.py:6-10); 12-bit is always BE */
+#define FRAD_RAW_BE_INTS   2u /* reproduce the reference's to_f64 quirk: big-endian integer PCM is NOT
+                                 normalised (pcmformat.py:37-45 compares against native dtypes only)  */
+
+/* ---- tables / bookkeeping ------------------------------------------------------------------ */
+int         frad_abi_version(void);
+const char* frad_strerror(int status);
+int         frad_last_hip_error(void);
+/* payload bytes of one frame: N*C*bits/8, 12-bit rounds the nibble count up (profile0.py:33-41). */
+size_t      frad_payload_bytes(int32_t N, int32_t C, int32_t bits);
+/* 1 if frad_p0_* runs the LDS-resident FFT kernel for this N (else the generic direct-sum kernel). */
+int         frad_has_fast_path(int32_t N, int32_t C, int32_t compute_f32);
+/* build the twiddle tables for (N, precision) on the current device now (hipMalloc + upload).   */
+int         frad_plan_prepare(int32_t N, int32_t compute_f32);
+void        frad_plan_clear(void);
+
+/* ---- profile 0: DCT archiving ----------------------------------------------------------------
+ * frad_p0_analogue  == fourier.profile0.analogue (src/libfrad/fourier/profile0.py:14-44) fused with
+ * to_f64 (backend/pcmformat.py:34-47) and the frame cut (encoder.py:72-93), batched.
+ *   pcm            first sample-frame of frame 0; frame i starts `frame_stride` sample-frames later
+ *   pcm_dtype      FRAD_PCM_*; integer and f64 input is transformed in f64, f32/f16 input in f32
+ *                  (the reference does not widen floats and pocketfft then stays in single)
+ *   bits           storage depth 12/16/24/32/48/64 (the caller applies `bits not in DEPTHS -> 16`)
+ *   payload        frame i's bytes start at payload + i*payload_stride (>= frad_payload_bytes)
+ *   absmax[i]      max |X| of frame i as float64 (NaN if any bin is NaN, like np.max): the caller
+ *                  compares it with the storage type's max and re-submits the rare frame that
+ *                  needs a deeper format (profile0.py:24-26).  May be NULL.
+ */
+int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C,
+                     int64_t frame_stride, int32_t bits, uint32_t flags,
+                     void* payload, int64_t payload_stride, double* absmax, void* stream);
+
+/* frad_p0_digital == fourier.profile0.digital (profile0.py:46-69): unpack, NaN/Inf -> 0, inverse
+ * DCT in float64, [N, C] interleaved float64 out (frame i at pcm_out + i*N*C).                    */
+int frad_p0_digital(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C,
+                    int32_t bits, uint32_t flags, double* pcm_out, void* stream);
+
+/* ---- profile 4: PCM archiving (same pack/unpack, no transform; profile4.py:14-41, 43-63) ------
+ * float32/float16 PCM is cast from single precision, everything else from float64, as numpy's
+ * astype does on the reference's arrays.                                                          */
+int frad_p4_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C,
+                     int64_t frame_stride, int32_t bits, uint32_t flags,
+                     void* payload, int64_t payload_stride, double* absmax, void* stream);
+int frad_p4_digital(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C,
+                    int32_t bits, uint32_t flags, double* pcm_out, void* stream);
+
+/* ---- profile 1: psychoacoustic quantiser, pre-/post-entropy halves ----------------------------
+ * frad_p1_analogue == fourier.profile1.analogue up to the two integer arrays (profile1.py:15-40 with
+ * p1tools.py:15-44).  `N` must be a legal compact frame size (fourier/profiles.py:14-23); frame i
+ * reads `n_valid` (<= N) sample-frames starting at pcm + i*frame_stride (frame_stride = hop when the
+ * encoder overlaps, encoder.py:35-51) and is zero-padded to N (profile1.py:19).
+ *   q   int32 [n_frames, N, C]  bin-major / channel-minor   (freqs_flat, profile1.py:34-36)
+ *   tq  int32 [n_frames, 27, C] band-major / channel-minor  (thres_flat, profile1.py:38-40)
+ * Exp-Golomb + deflate (profile1.py:43-50) stay on the host.                                       */
+int frad_p1_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C,
+                     int64_t frame_stride, int32_t n_valid, int32_t bits, int32_t srate, double loss_level,
+                     uint32_t flags, int32_t* q, int32_t* tq, void* stream);
+
+/* frad_p1_digital == fourier.profile1.digital from the decoded integers on (profile1.py:65-77):
+ * dequantise, spread the 27 thresholds over the bins, inverse DCT -> float64 [n_frames, N, C].
+ * With overlap_ratio > 1 it also applies the decoder's Hann cross-fade between consecutive frames of
+ * the batch (decoder.py:28-46): out_ola [n_frames, N - N/ratio... see DESIGN.md] -- when `ola_out`
+ * is non-NULL frame i contributes rows [0, cut) faded against frame i-1's tail (`prev_tail` for i=0,
+ * may be NULL = no previous frame) and the last frame's tail is returned in `next_tail`.           */
+int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32_t N, int32_t C,
+                    int32_t bits, int32_t srate, double* pcm_out, void* stream);
+int frad_p1_overlap_add(const double* frames, int64_t n_frames, int32_t N, int32_t C, int32_t overlap_ratio,
+                        const double* prev_tail, double* ola_out, double* next_tail, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRAD_HIP_H */
