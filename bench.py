@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's configuration.
+
+Metric   : Msamples/s encode+decode, 48 kHz stereo, frame = 2048 (sample = one PCM value).
+Workload : configs[1] -- 10 min of 48 kHz stereo s16le PCM, profile 0 (DCT archiving), 32-bit
+           big-endian storage, N = 2048: 14 062 full frames + the 1 024-sample tail frame, batched
+           on one MI355X.  Synthetic "signal A" (harmonic mix + -60 dBFS noise), generated on the GPU.
+Step     : one pass of the hot path over the whole clip: analogue (encode) of every frame, then
+           digital (decode) of every payload; inputs are resident in HBM when the clock starts.
+N > 1    : frames are independent -> every rank owns one such clip (weak scaling), no collective
+           on the data path; the only collectives are the timing barrier and the max-reduce.
+
+Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel: algorithmic bytes per launch
+(encode B_in + b/8 = 6 B/sample, decode b/8 + 8 = 12 B/sample) / its mean HIP-event time.
+`cpu_baseline` times the oracle (NumPy/SciPy restatement of the reference path) on this host.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from frad_python_amd import core  # noqa: E402
+
+SRATE, CHANNELS, FSIZE, BITS = 48000, 2, 2048, 32
+SECONDS = 600
+HBM_PEAK_GBS = 8000.0                     # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def signal_a_gpu(n: int, channels: int, srate: int, seed: int, device) -> torch.Tensor:
+    """"Signal A" of SURVEY 8d as s16le, synthesised on the device: 8 partials of 110*(c+1) Hz with
+    0.5 Hz AM, peak 0.8, plus -60 dBFS white noise."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    t = torch.arange(n, dtype=torch.float64, device=device) / srate
+    out = torch.empty((n, channels), dtype=torch.float64, device=device)
+    for c in range(channels):
+        ph = torch.rand(8, generator=g, device=device, dtype=torch.float64) * 2 * np.pi
+        x = torch.zeros(n, dtype=torch.float64, device=device)
+        for h in range(8):
+            x += torch.sin(2 * np.pi * 110.0 * (c + 1) * (h + 1) * t + ph[h]) / (h + 1)
+        x *= 0.75 + 0.25 * torch.sin(2 * np.pi * 0.5 * t + c)
+        out[:, c] = x
+    out *= 0.8 / out.abs().max()
+    out += torch.randn((n, channels), generator=g, device=device, dtype=torch.float64) * 1e-3
+    return torch.clamp(torch.round(out * 32768.0), -32768, 32767).to(torch.int16)
+
+
+class Workload:
+    def __init__(self, device, seed):
+        self.n_total = SRATE * SECONDS                        # sample-frames
+        self.n_full = self.n_total // FSIZE                   # 14062
+        self.tail = self.n_total - self.n_full * FSIZE        # 1024
+        self.pcm = signal_a_gpu(self.n_total, CHANNELS, SRATE, seed, device)
+        self.samples = self.n_total * CHANNELS
+        lib = core._lib.load()
+        lib.plan_prepare(FSIZE, False)
+        if self.tail:
+            lib.plan_prepare(self.tail, False)
+        nb = lib.payload_bytes(FSIZE, CHANNELS, BITS)
+        self.pay = torch.empty((self.n_full, nb), dtype=torch.uint8, device=device)
+        self.absmax = torch.empty(self.n_full, dtype=torch.float64, device=device)
+        self.out = torch.empty((self.n_full, FSIZE, CHANNELS), dtype=torch.float64, device=device)
+        if self.tail:
+            nbt = lib.payload_bytes(self.tail, CHANNELS, BITS)
+            self.pay_t = torch.empty((1, nbt), dtype=torch.uint8, device=device)
+            self.absmax_t = torch.empty(1, dtype=torch.float64, device=device)
+            self.out_t = torch.empty((1, self.tail, CHANNELS), dtype=torch.float64, device=device)
+        self.tail_pcm = self.pcm[self.n_full * FSIZE:]
+        self.over = torch.zeros((), dtype=torch.bool, device=device)
+
+    def encode(self, ev=None):
+        if ev: ev[0].record()
+        core.analogue_batch(0, self.pcm, "s16le", self.n_full, FSIZE, CHANNELS, BITS, False,
+                            check_overflow=False, out=self.pay, absmax=self.absmax)
+        if ev: ev[1].record()
+        if self.tail:
+            core.analogue_batch(0, self.tail_pcm, "s16le", 1, self.tail, CHANNELS, BITS, False,
+                                check_overflow=False, out=self.pay_t, absmax=self.absmax_t)
+
+    def decode(self, ev=None):
+        if ev: ev[0].record()
+        core.digital_batch(0, self.pay, self.n_full, FSIZE, CHANNELS, BITS, False, out=self.out)
+        if ev: ev[1].record()
+        if self.tail:
+            core.digital_batch(0, self.pay_t, 1, self.tail, CHANNELS, BITS, False, out=self.out_t)
+
+    def overflow_check(self):
+        """The reference's per-frame overflow test (profile0.py:24-26): evaluated on the device every
+        step over all frames; the host reads the sticky flag once, after the timed region."""
+        self.over |= (self.absmax > core.FLOAT_MAX[BITS]).any()
+        if self.tail:
+            self.over |= (self.absmax_t > core.FLOAT_MAX[BITS]).any()
+
+
+def cpu_baseline(pcm_host: np.ndarray, n_frames: int):
+    """Oracle, one frame at a time on one core -- the reference's own cost profile (encoder.py:60,
+    decoder.py:55 loop one frame per iteration through numpy/scipy)."""
+    from oracle import frad_oracle as fo
+    dt = fo.pcm_dtype("s16le")
+    t0 = time.perf_counter()
+    for f in range(n_frames):
+        frame = fo.to_f64(pcm_host[f * FSIZE:(f + 1) * FSIZE], dt)
+        frad, idx, ch, sr = fo.p0_analogue(frame, BITS, SRATE, False)
+        fo.p0_digital(frad, idx, ch, False)
+    dt_s = time.perf_counter() - t0
+    return n_frames * FSIZE * CHANNELS / dt_s / 1e6, dt_s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    wl = Workload(dev, seed=1234 + rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wl.encode(); wl.decode(); wl.overflow_check()
+    ev_enc = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev_dec = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        wl.encode(ev_enc[i])
+        wl.decode(ev_dec[i])
+        wl.overflow_check()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert not bool(wl.over), "synthetic audio must not overflow float32 storage"
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_enc]))
+    dec_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_dec]))
+    full = wl.n_full * FSIZE * CHANNELS                      # samples one main launch processes
+    enc_bytes, dec_bytes = full * (2 + BITS // 8), full * (BITS // 8 + 8)
+
+    def roof(name, nbytes, ms):
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": nbytes,
+                "avg_launch_ms": round(ms, 4)}
+    r_enc = roof("k_p0_fwd<double,10,1> (load+to_f64+DCT-II+absmax+f32 cast+BE pack)", enc_bytes, enc_ms)
+    r_dec = roof("k_p0_inv<10> (unpack+scrub+inverse DCT+f64 interleaved store)", dec_bytes, dec_ms)
+    dominant, other = (r_dec, r_enc) if dec_ms >= enc_ms else (r_enc, r_dec)
+
+    if rank == 0:
+        value = world * wl.samples * args.steps / elapsed / 1e6
+        line = {
+            "metric": "Msamples/s encode+decode, 48 kHz stereo frame=2048; achieved HBM GB/s vs peak",
+            "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: 10 min 48 kHz stereo s16le, profile 0, bits=32 BE, frame=2048, "
+                                   "14062 frames + 1024-sample tail per GPU, encode then decode",
+                       "frames_per_gpu": wl.n_full + (1 if wl.tail else 0), "samples_per_gpu": wl.samples,
+                       "parallelism": f"frames sharded over {world} GPU(s), no collectives"},
+            "roofline": dominant, "roofline_other": other,
+            "hbm_frac_enc_plus_dec": round((enc_bytes + dec_bytes) / ((enc_ms + dec_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            n = wl.n_full
+            host = wl.pcm[:n * FSIZE].cpu().numpy()
+            v, secs = cpu_baseline(host, n)
+            line["cpu_baseline"] = {"value": round(v, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                                    "sample": f"{n} frames of the same clip ({n * FSIZE * CHANNELS} samples), one frame "
+                                              f"per call like the reference loop, {secs:.1f} s of CPU work",
+                                    "host_cpus": os.cpu_count()}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+"""Batched operators of the transform core on PyTorch-ROCm tensors.
+
+One call = one HIP launch over ``n_frames`` independent frames (the reference runs one frame
+per call through ``fourier.profileN.analogue/digital``, src/libfrad/encoder.py:96-100 and
+decoder.py:70-74).  Tensors only carry device memory and the current stream into the C-ABI
+(include/frad_hip.h); all arithmetic happens in libfrad_hip.so.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from .backend.pcmformat import itemsize_of, pcm_dtype_code
+
+DEPTHS = (12, 16, 24, 32, 48, 64)                      # ref: fourier/profile0.py:4, profile4.py:4
+# largest finite value of each depth's storage float (ref: profile0.py:6-13 FLOAT_DR)
+FLOAT_MAX = {12: 65504.0, 16: 65504.0, 24: float(np.finfo("f4").max), 32: float(np.finfo("f4").max),
+             48: float(np.finfo("f8").max), 64: float(np.finfo("f8").max)}
+_ESCALATE = {12: 16, 16: 24, 24: 32, 32: 48, 48: 64, 64: 128}
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must live in MI355X device memory (got a {t.device} tensor); "
+                           "the transform core has no CPU path")
+    if not t.is_contiguous():
+        raise ValueError(f"{what} must be contiguous")
+
+
+def _stream_ptr() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def _align16(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+def escalate_depth(absmax: float, bits: int) -> int:
+    """The reference's overflow loop (profile0.py:24-26): NaN never escalates, +Inf raises."""
+    while absmax > FLOAT_MAX[bits]:
+        bits = _ESCALATE[bits]
+        if bits == 128:
+            raise OverflowError("Overflow with reaching the max bit depth.")
+    return bits
+
+
+@dataclass
+class EncodedBatch:
+    """Payloads of one batched ``analogue`` call.
+
+    ``payload[i, :nbytes]`` is frame i at the requested depth.  A frame whose transform exceeds the
+    storage float's range (profile0.py:24-26) is listed in ``escalated`` as
+    ``{frame: (payload_row_tensor, bits)}`` at the deeper format the reference would pick."""
+    payload: torch.Tensor            # uint8 [n_frames, stride]
+    nbytes: int
+    bits: int
+    absmax: torch.Tensor             # float64 [n_frames]
+    escalated: dict
+
+    def frame_bytes(self, i: int) -> tuple[bytes, int]:
+        if i in self.escalated:
+            row, bits = self.escalated[i]
+            return bytes(row.cpu().numpy()), bits
+        return bytes(self.payload[i, :self.nbytes].cpu().numpy()), self.bits
+
+
+def analogue_batch(profile: int, pcm: torch.Tensor, pcm_format: str, n_frames: int, N: int, C: int, bits: int,
+                   little_endian: bool = False, *, frame_stride: int | None = None, raw_be_ints: bool = True,
+                   check_overflow: bool = True, out: torch.Tensor | None = None,
+                   absmax: torch.Tensor | None = None) -> EncodedBatch:
+    """Profile 0 (DCT) or 4 (PCM) ``analogue`` over a batch of frames.
+
+    ``pcm`` is the raw interleaved PCM (any tensor dtype; ``pcm_format`` names the element type as
+    the reference's CLI does, e.g. ``s16le``), frame i starting ``frame_stride`` (default N)
+    sample-frames after frame i-1."""
+    _require_cuda(pcm, "pcm")
+    if bits not in DEPTHS:
+        bits = 16                                         # ref: profile0.py:15
+    lib = _lib.load()
+    code = pcm_dtype_code(pcm_format)
+    stride_frames = N if frame_stride is None else frame_stride
+    need = ((n_frames - 1) * stride_frames + N) * C * itemsize_of(code) if n_frames else 0
+    if pcm.numel() * pcm.element_size() < need:
+        raise ValueError(f"pcm holds {pcm.numel() * pcm.element_size()} bytes, {need} needed")
+    nbytes = lib.payload_bytes(N, C, bits)
+    stride = _align16(nbytes)
+    if out is None:
+        out = torch.empty((n_frames, stride), dtype=torch.uint8, device=pcm.device)
+    if absmax is None:
+        absmax = torch.empty(n_frames, dtype=torch.float64, device=pcm.device)
+    flags = (int(little_endian) * _lib.FRAD_LITTLE_ENDIAN) | (int(raw_be_ints) * _lib.FRAD_RAW_BE_INTS)
+    fn = lib.p4_analogue if profile == 4 else lib.p0_analogue
+    with torch.cuda.device(pcm.device):
+        fn(pcm.data_ptr(), code, n_frames, N, C, stride_frames, bits, flags, out.data_ptr(), out.stride(0),
+           absmax.data_ptr(), _stream_ptr())
+    escalated = {}
+    if check_overflow and n_frames:
+        over = absmax > FLOAT_MAX[bits]                   # NaN compares False, as in the reference
+        if bool(over.any()):
+            isz = itemsize_of(code)
+            flat = pcm.reshape(-1).view(torch.uint8)
+            for i in over.nonzero().flatten().tolist():
+                deeper = escalate_depth(float(absmax[i]), bits)
+                start = i * stride_frames * C * isz
+                one = analogue_batch(profile, flat[start:start + N * C * isz].clone(), pcm_format, 1, N, C, deeper,
+                                     little_endian, raw_be_ints=raw_be_ints, check_overflow=False)
+                escalated[i] = (one.payload[0, :one.nbytes], deeper)
+    return EncodedBatch(out, nbytes, bits, absmax, escalated)
+
+
+def digital_batch(profile: int, payload: torch.Tensor, n_frames: int, N: int, C: int, bits: int,
+                  little_endian: bool = False, *, payload_stride: int | None = None,
+                  out: torch.Tensor | None = None) -> torch.Tensor:
+    """Profile 0 / 4 ``digital`` over a batch: uint8 payload rows -> float64 [n_frames, N, C]."""
+    _require_cuda(payload, "payload")
+    lib = _lib.load()
+    nbytes = lib.payload_bytes(N, C, bits)
+    if payload_stride is None:
+        payload_stride = payload.stride(0) if payload.dim() == 2 else nbytes
+    if payload.numel() * payload.element_size() < ((n_frames - 1) * payload_stride + nbytes if n_frames else 0):
+        raise ValueError("payload tensor is smaller than n_frames frames")
+    if out is None:
+        out = torch.empty((n_frames, N, C), dtype=torch.float64, device=payload.device)
+    flags = int(little_endian) * _lib.FRAD_LITTLE_ENDIAN
+    fn = lib.p4_digital if profile == 4 else lib.p0_digital
+    with torch.cuda.device(payload.device):
+        fn(payload.data_ptr(), payload_stride, n_frames, N, C, bits, flags, out.data_ptr(), _stream_ptr())
+    return out

@@ -254,8 +254,9 @@ int frad_p4_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
                      int32_t bits, uint32_t flags, void* payload, int64_t payload_stride, double* absmax, void* stream) {
     int rc = check_common(pcm, payload, n_frames, N, C, bits);
     if (rc != FRAD_OK) return rc;
-    if (!valid_dtype(pcm_dtype) || payload_stride < (int64_t)frad_payload_bytes(N, C, bits)) return FRAD_E_INVALID;
+    if (!valid_dtype(pcm_dtype)) return FRAD_E_INVALID;
     if (n_frames == 0) return FRAD_OK;
+    if (payload_stride < (int64_t)frad_payload_bytes(N, C, bits)) return FRAD_E_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (absmax) HIPCHK(hipMemsetAsync(absmax, 0, sizeof(double) * (size_t)n_frames, s));
     const int lg = (pcm_dtype >> 1) & 3;
@@ -288,8 +289,8 @@ int frad_p4_digital(const void* payload, int64_t payload_stride, int64_t n_frame
                     uint32_t flags, double* pcm_out, void* stream) {
     int rc = check_common(payload, pcm_out, n_frames, N, C, bits);
     if (rc != FRAD_OK) return rc;
-    if (payload_stride < (int64_t)frad_payload_bytes(N, C, bits)) return FRAD_E_INVALID;
     if (n_frames == 0) return FRAD_OK;
+    if (payload_stride < (int64_t)frad_payload_bytes(N, C, bits)) return FRAD_E_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Geom g = make_geom(n_frames, N, C, N, payload_stride, bits, flags, FRAD_PCM_F64LE);
     const long long NC = (long long)N * C;
@@ -319,8 +320,9 @@ int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
                      int32_t bits, uint32_t flags, void* payload, int64_t payload_stride, double* absmax, void* stream) {
     int rc = check_common(pcm, payload, n_frames, N, C, bits);
     if (rc != FRAD_OK) return rc;
-    if (!valid_dtype(pcm_dtype) || payload_stride < (int64_t)frad_payload_bytes(N, C, bits)) return FRAD_E_INVALID;
+    if (!valid_dtype(pcm_dtype)) return FRAD_E_INVALID;
     if (n_frames == 0) return FRAD_OK;
+    if (payload_stride < (int64_t)frad_payload_bytes(N, C, bits)) return FRAD_E_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int lg = (pcm_dtype >> 1) & 3;
     const bool f32 = (pcm_dtype >> 3) == 2 && lg <= 2;
@@ -360,8 +362,8 @@ int frad_p0_digital(const void* payload, int64_t payload_stride, int64_t n_frame
                     uint32_t flags, double* pcm_out, void* stream) {
     int rc = check_common(payload, pcm_out, n_frames, N, C, bits);
     if (rc != FRAD_OK) return rc;
-    if (payload_stride < (int64_t)frad_payload_bytes(N, C, bits)) return FRAD_E_INVALID;
     if (n_frames == 0) return FRAD_OK;
+    if (payload_stride < (int64_t)frad_payload_bytes(N, C, bits)) return FRAD_E_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Geom g = make_geom(n_frames, N, C, N, payload_stride, bits, flags, FRAD_PCM_F64LE);
     const int ai = (aligned16(payload) && payload_stride % 16 == 0) ? 1 : 0;

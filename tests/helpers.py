@@ -1,0 +1,146 @@
+"""Shared plumbing of the parity tests.
+
+Two ways to reach the kernels, same C-ABI either way:
+  * ``GpuBackend``  -- the product path: frad_python_amd.core on cuda:0 (libfrad_hip.so, gfx950);
+  * ``EmuBackend``  -- tests/emu: the same kernel source interpreted on the CPU (no GPU needed),
+                       used by the ``-m "not gpu"`` suite to check indexing/packing logic.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU_LIB = os.path.join(EMU_DIR, "libfrad_emu.so")
+CSRC = os.path.join(ROOT, "frad_python_amd", "csrc")
+
+
+def build_emulator() -> str:
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
+    srcs += [os.path.join(EMU_DIR, "hip_emu.hpp"), os.path.join(ROOT, "include", "frad_hip.h")]
+    if not os.path.exists(EMU_LIB) or any(os.path.getmtime(s) > os.path.getmtime(EMU_LIB) for s in srcs):
+        subprocess.run([os.path.join(EMU_DIR, "build_emu.sh")], check=True)
+    return EMU_LIB
+
+
+def _align16(n):
+    return (n + 15) // 16 * 16
+
+
+class EmuBackend:
+    name = "emu"
+
+    def __init__(self):
+        from frad_python_amd._lib import FradLib
+        self.lib = FradLib(build_emulator())
+
+    def analogue(self, profile, raw: np.ndarray, fmt, F, N, C, bits, le, frame_stride=None, raw_be=True,
+                 offset=0, pad_stride=0):
+        """raw: contiguous ndarray of PCM elements.  ``offset`` (bytes) mis-aligns both buffers."""
+        from frad_python_amd.backend.pcmformat import pcm_dtype_code
+        pb = self.lib.payload_bytes(N, C, bits if bits in (12, 16, 24, 32, 48, 64) else 16)
+        stride = (_align16(pb) if not offset else pb) + pad_stride
+        src = np.zeros(raw.nbytes + offset + 64, np.uint8)
+        src[offset:offset + raw.nbytes] = raw.view(np.uint8).reshape(-1)
+        pay = np.zeros(F * stride + offset + 64, np.uint8)
+        am = np.zeros(max(F, 1))
+        fn = self.lib.p4_analogue if profile == 4 else self.lib.p0_analogue
+        flags = int(le) | (2 if raw_be else 0)
+        fn(src.ctypes.data + offset, pcm_dtype_code(fmt), F, N, C, N if frame_stride is None else frame_stride, bits,
+           flags, pay.ctypes.data + offset, stride, am.ctypes.data)
+        return pay[offset:offset + F * stride].reshape(F, stride)[:, :pb].copy(), am[:F]
+
+    def digital(self, profile, payload: np.ndarray, F, N, C, bits, le, offset=0):
+        pb = payload.shape[1] if F else 0
+        stride = _align16(pb) if not offset else pb
+        buf = np.zeros(F * stride + offset + 64, np.uint8)
+        if F:
+            buf[offset:offset + F * stride].reshape(F, stride)[:, :pb] = payload
+        out = np.zeros((max(F, 1), N, C))
+        fn = self.lib.p4_digital if profile == 4 else self.lib.p0_digital
+        fn(buf.ctypes.data + offset, stride, F, N, C, bits, int(le), out.ctypes.data)
+        return out[:F]
+
+
+class GpuBackend:
+    name = "gpu"
+
+    def __init__(self):
+        import torch
+        assert torch.cuda.is_available()
+        self.torch = torch
+        self.dev = torch.device("cuda:0")
+
+    def analogue(self, profile, raw, fmt, F, N, C, bits, le, frame_stride=None, raw_be=True, offset=0, pad_stride=0):
+        from frad_python_amd import core
+        t = self.torch
+        src = t.zeros(raw.nbytes + offset + 64, dtype=t.uint8, device=self.dev)
+        src[offset:offset + raw.nbytes] = t.from_numpy(raw.view(np.uint8).reshape(-1).copy()).to(self.dev)
+        out = None
+        pb = core._lib.load().payload_bytes(N, C, bits if bits in core.DEPTHS else 16)
+        if offset or pad_stride:
+            stride = (pb if offset else _align16(pb)) + pad_stride
+            flat = t.zeros(F * stride + offset + 64, dtype=t.uint8, device=self.dev)
+            out = flat[offset:offset + F * stride].view(F, stride) if F else flat[:0].view(0, stride)
+        enc = core.analogue_batch(profile, src[offset:], fmt, F, N, C, bits, le, frame_stride=frame_stride,
+                                  raw_be_ints=raw_be, check_overflow=False, out=out)
+        t.cuda.synchronize()
+        return enc.payload[:, :enc.nbytes].cpu().numpy(), enc.absmax.cpu().numpy()
+
+    def digital(self, profile, payload, F, N, C, bits, le, offset=0):
+        from frad_python_amd import core
+        t = self.torch
+        pb = payload.shape[1] if F else 0
+        stride = _align16(pb) if not offset else pb
+        flat = t.zeros(F * stride + offset + 64, dtype=t.uint8, device=self.dev)
+        view = flat[offset:offset + F * stride].view(F, stride) if F else flat[:0].view(0, max(stride, 1))
+        if F:
+            view[:, :pb] = t.from_numpy(np.ascontiguousarray(payload)).to(self.dev)
+        out = core.digital_batch(profile, view, F, N, C, bits, le, payload_stride=stride)
+        t.cuda.synchronize()
+        return out.cpu().numpy()
+
+
+def oracle_frames(fo, profile, raw, fmt, F, N, C, bits, le, frame_stride=None, raw_be=True):
+    """Per-frame oracle results: list of (payload bytes, depth_idx, decoded f64, absmax)."""
+    dt = fo.pcm_dtype(fmt)
+    hop = N if frame_stride is None else frame_stride
+    flat = raw.reshape(-1, C)
+    res = []
+    for f in range(F):
+        frame = fo.to_f64(flat[f * hop:f * hop + N], dt, be_int_quirk=raw_be)
+        if profile == 0:
+            X = fo.dct_channels(frame)
+            am = np.max(np.abs(X)) if X.size else 0.0
+            frad = fo.pack_floats(X.T.ravel(), bits, le)          # depth held fixed (escalation tested apart)
+            dec = fo.p0_digital(frad, fo.DEPTHS.index(bits), C, le)
+        else:
+            am = np.max(np.abs(frame)) if frame.size else 0.0
+            frad = fo.pack_floats(np.asarray(frame).ravel(), bits, le)
+            dec = fo.p4_digital(frad, fo.DEPTHS.index(bits), C, le)
+        res.append((np.frombuffer(frad, np.uint8), dec, float(am)))
+    return res
+
+
+def word_mismatches(a: np.ndarray, b: np.ndarray, bits: int) -> int:
+    """Number of stored values (not bytes) that differ between two payloads of one frame."""
+    if bits == 12:
+        return int(np.count_nonzero(unpack12(a) != unpack12(b)))
+    nb = bits // 8
+    n = min(a.size, b.size) // nb
+    return int(np.count_nonzero((a[:n * nb].reshape(n, nb) != b[:n * nb].reshape(n, nb)).any(axis=1)))
+
+
+def unpack12(buf: np.ndarray) -> np.ndarray:
+    nib = np.empty(buf.size * 2, np.uint16)
+    nib[0::2], nib[1::2] = buf >> 4, buf & 15
+    n = nib.size // 3
+    t = nib[:n * 3].reshape(n, 3)
+    return (t[:, 0] << 8) | (t[:, 1] << 4) | t[:, 2]
+
+
+def payload_values(fo, buf: np.ndarray, bits: int, le: bool) -> np.ndarray:
+    return fo.unpack_floats(buf.tobytes(), bits, le)

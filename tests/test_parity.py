@@ -1,0 +1,250 @@
+"""Parity of the HIP transform core with the oracle (and through it with the reference).
+
+Every test runs twice: ``gpu`` = the product path on a real MI355X (marked, run with -m gpu) and
+``emu`` = the same kernels interpreted on the CPU (tests/emu), part of the CPU suite.
+
+Tolerances, all asserted below:
+  * profile 4 and every pack/unpack: bit-exact;
+  * profile 0, f64 compute (int / f64 PCM): payload bit-identical at b <= 32 up to a 1e-5 fraction
+    of double-rounding ties; b = 48/64: |dX| <= 8 eps64 max|X| log2 N;
+  * profile 0, f32 compute (f32 / f16 PCM): |dX| <= 8 eps32 max|X| log2 N;
+  * decoded PCM: |dx| <= 8 eps64 log2(N) max(1, max|x|) against the oracle decoding the same payload.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_json, load_npz
+from helpers import EmuBackend, GpuBackend, oracle_frames, payload_values, word_mismatches
+from frad_python_amd import synth
+from oracle import frad_oracle as fo
+
+EPS64, EPS32 = 2.220446049250313e-16, 1.1920929e-07
+_backends = {}
+
+
+@pytest.fixture(params=[pytest.param("emu"), pytest.param("gpu", marks=pytest.mark.gpu)])
+def be(request):
+    if request.param not in _backends:
+        _backends[request.param] = EmuBackend() if request.param == "emu" else GpuBackend()
+    return _backends[request.param]
+
+
+def _sizes(be, emu, gpu):
+    return emu if be.name == "emu" else gpu
+
+
+def check_p0_payload(got, want, bits, le, fmt, N):
+    """Payload of one frame against the oracle's, per the tolerance contract."""
+    f32 = fmt.startswith(("f32", "f16"))
+    gv, wv = payload_values(fo, got, bits, le), payload_values(fo, want, bits, le)
+    scale = max(np.max(np.abs(wv)), 1e-300)
+    lg = max(np.log2(N), 1.0)
+    if f32:
+        store_eps = {12: 2.0 ** -7, 16: 2.0 ** -10, 24: 2.0 ** -15, 32: 0, 48: 0, 64: 0}[bits]
+        assert np.max(np.abs(gv - wv)) <= 8 * EPS32 * scale * lg + store_eps * scale
+        return 0
+    if bits >= 48:
+        # 48 bit = float64 truncated to 36 explicit mantissa bits: a last-bit difference before the
+        # truncation can move the stored word by one 2^-36 step
+        quantum = np.abs(wv) * 2.0 ** -36 if bits == 48 else 0.0
+        assert np.all(np.abs(gv - wv) <= 8 * EPS64 * scale * lg + quantum)
+        return 0
+    return word_mismatches(got, want, bits)
+
+
+@pytest.mark.parametrize("fmt", ["s16le", "f64le", "f32le", "u8", "s32be", "f16le", "s64le", "u16be", "f64be", "s8"])
+def test_p4_bit_exact_all_depths(be, fmt):
+    rng = np.random.default_rng(11)
+    for (N, C, F) in _sizes(be, [(2048, 2, 2), (5, 1, 3), (33, 3, 2)], [(2048, 2, 5), (5, 1, 3), (33, 3, 2), (4096, 8, 2), (1, 1, 1)]):
+        raw = synth.to_pcm(rng.uniform(-1, 1, (F * N, C)), fmt)
+        for bits in fo.DEPTHS:
+            for le in (False, True):
+                pay, am = be.analogue(4, raw, fmt, F, N, C, bits, le)
+                ref = oracle_frames(fo, 4, raw, fmt, F, N, C, bits, le)
+                for f in range(F):
+                    assert np.array_equal(pay[f], ref[f][0]), (fmt, N, C, bits, le, f)
+                    assert am[f] == ref[f][2]
+                dec = be.digital(4, pay, F, N, C, bits, le)
+                for f in range(F):
+                    assert np.array_equal(dec[f], ref[f][1])
+
+
+def test_p4_unaligned_buffers_and_strides(be):
+    rng = np.random.default_rng(12)
+    N, C, F = 100, 3, 3
+    raw = synth.to_pcm(rng.uniform(-1, 1, (F * N, C)), "s16le")
+    for bits in fo.DEPTHS:
+        ref = oracle_frames(fo, 4, raw, "s16le", F, N, C, bits, False)
+        for offset, pad in ((2, 0), (0, 16), (6, 3)):
+            pay, am = be.analogue(4, raw, "s16le", F, N, C, bits, False, offset=offset, pad_stride=pad)
+            for f in range(F):
+                assert np.array_equal(pay[f], ref[f][0]), (bits, offset, pad)
+            dec = be.digital(4, pay, F, N, C, bits, False, offset=offset)
+            for f in range(F):
+                assert np.array_equal(dec[f], ref[f][1])
+
+
+@pytest.mark.parametrize("fmt", ["s16le", "f64le", "f32le"])
+def test_p0_fft_sizes(be, fmt):
+    rng = np.random.default_rng(13)
+    shapes = _sizes(be, [(2048, 2, 3), (128, 1, 5), (256, 3, 2), (512, 2, 2), (1024, 1, 2), (4096, 2, 1)],
+                    [(2048, 2, 9), (128, 1, 5), (256, 3, 4), (512, 2, 4), (1024, 1, 3), (4096, 2, 3), (4096, 8, 3),
+                     (8192, 1, 2), (16384, 1, 2), (2048, 8, 3), (128, 5, 3), (2048, 1, 5)])
+    for (N, C, F) in shapes:
+        x = rng.uniform(-1, 1, (F * N, C))
+        x[:N] = synth.harmonic_mix(N, C, 48000, seed=N)          # one realistic frame, the rest full-scale noise
+        raw = synth.to_pcm(x, fmt)
+        for bits in fo.DEPTHS:
+            pay, am = be.analogue(0, raw, fmt, F, N, C, bits, False)
+            ref = oracle_frames(fo, 0, raw, fmt, F, N, C, bits, False)
+            mism, words = 0, 0
+            for f in range(F):
+                mism += check_p0_payload(pay[f], ref[f][0], bits, False, fmt, N)
+                words += N * C
+                tol = (8 * EPS32 if fmt == "f32le" else 8 * EPS64) * max(ref[f][2], 1e-300) * np.log2(N)
+                assert abs(am[f] - ref[f][2]) <= tol
+            assert mism <= max(1, int(2e-5 * words)), (fmt, N, C, bits, mism, words)
+            # decode the ORACLE's payload with the kernel: isolates the inverse transform
+            want = np.stack([r[0] for r in ref])
+            dec = be.digital(0, want, F, N, C, bits, False)
+            for f in range(F):
+                assert np.max(np.abs(dec[f] - ref[f][1])) <= 8 * EPS64 * np.log2(N) * max(1.0, np.max(np.abs(ref[f][1])))
+
+
+def test_p0_little_endian_and_unaligned(be):
+    rng = np.random.default_rng(14)
+    N, C, F = 512, 2, 2
+    raw = synth.to_pcm(rng.uniform(-1, 1, (F * N, C)), "s16le")
+    for bits in (16, 24, 32, 48, 64):
+        ref = oracle_frames(fo, 0, raw, "s16le", F, N, C, bits, True)
+        for offset in (0, 2):
+            pay, am = be.analogue(0, raw, "s16le", F, N, C, bits, True, offset=offset)
+            for f in range(F):
+                assert check_p0_payload(pay[f], ref[f][0], bits, True, "s16le", N) == 0
+            dec = be.digital(0, np.stack([r[0] for r in ref]), F, N, C, bits, True, offset=offset)
+            for f in range(F):
+                assert np.max(np.abs(dec[f] - ref[f][1])) <= 8 * EPS64 * 9
+
+
+@pytest.mark.parametrize("fmt", ["s16le", "f32le"])
+def test_p0_any_length_direct_kernel(be, fmt):
+    """Tail frames and odd sizes (SURVEY hard part 4): 896 = 48000 mod 2048, primes, tiny frames."""
+    rng = np.random.default_rng(15)
+    for (N, C, F) in _sizes(be, [(896, 2, 1), (7, 3, 2), (1, 1, 2), (2, 2, 1), (100, 1, 1)],
+                            [(896, 2, 3), (7, 3, 2), (1, 1, 2), (2, 2, 1), (100, 1, 2), (997, 2, 2), (1000, 2, 1), (64, 2, 2), (1920, 2, 1)]):
+        raw = synth.to_pcm(rng.uniform(-1, 1, (F * N, C)), fmt)
+        for bits in (12, 32, 64):
+            pay, am = be.analogue(0, raw, fmt, F, N, C, bits, False)
+            ref = oracle_frames(fo, 0, raw, fmt, F, N, C, bits, False)
+            for f in range(F):
+                gv, wv = payload_values(fo, pay[f], bits, False), payload_values(fo, ref[f][0], bits, False)
+                eps = {12: 2.0 ** -7, 32: 2.0 ** -23, 64: 0}[bits] + (8 * EPS32 if fmt == "f32le" else 8 * EPS64) * max(np.log2(N), 1)
+                assert np.max(np.abs(gv - wv)) <= eps * max(np.max(np.abs(wv)), 1e-300) * 2
+            dec = be.digital(0, np.stack([r[0] for r in ref]), F, N, C, bits, False)
+            for f in range(F):
+                assert np.max(np.abs(dec[f] - ref[f][1])) <= 16 * EPS64 * max(np.log2(N), 1) * max(1.0, np.max(np.abs(ref[f][1])))
+
+
+def test_overlapped_frame_gather(be):
+    """frame_stride < N: the encoder's overlap read (encoder.py:35-51) as a strided gather."""
+    rng = np.random.default_rng(16)
+    N, C, F, hop = 256, 2, 4, 240
+    raw = synth.to_pcm(rng.uniform(-1, 1, ((F - 1) * hop + N, C)), "s16le")
+    for profile in (0, 4):
+        pay, am = be.analogue(profile, raw, "s16le", F, N, C, 32, False, frame_stride=hop)
+        ref = oracle_frames(fo, profile, raw, "s16le", F, N, C, 32, False, frame_stride=hop)
+        for f in range(F):
+            assert np.array_equal(pay[f], ref[f][0])
+
+
+def test_nan_inf_scrub_and_absmax_semantics(be, g5):
+    pay = g5["scrub_payload"].reshape(1, -1)
+    assert np.array_equal(be.digital(4, pay, 1, 8, 1, 32, False)[0], g5["scrub_p4_dec"])
+    np.testing.assert_allclose(be.digital(0, pay, 1, 8, 1, 32, False)[0], g5["scrub_p0_dec"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(be.digital(0, pay, 1, 4, 2, 32, False)[0], g5["scrub_p0_dec_c2"], rtol=0, atol=1e-15)
+    x = g5["nan_in"]                                         # a NaN sample: np.max -> NaN, stored as NaN
+    for bits in (16, 32, 64):
+        got, am = be.analogue(4, x.astype("<f8"), "f64le", 1, 8, 1, bits, False)
+        assert np.array_equal(got[0], g5[f"nan_p4_b{bits}_frad"])
+        assert np.isnan(am[0])
+    big = np.array([[1e6], [0.5], [-0.25], [0.125]])         # overflow of f16: absmax tells the host to escalate
+    for profile in (0, 4):
+        got, am = be.analogue(profile, big.astype("<f8"), "f64le", 1, 4, 1, 16, False)
+        assert am[0] > 65504
+    got, am = be.analogue(4, np.array([[-np.inf], [1.0]]).astype("<f8"), "f64le", 1, 2, 1, 32, False)
+    assert am[0] == np.inf
+
+
+def test_empty_batch(be):
+    pay, am = be.analogue(0, np.zeros(0, np.int16), "s16le", 0, 2048, 2, 32, False)
+    assert pay.shape[0] == 0
+    assert be.digital(0, np.zeros((0, 16384), np.uint8), 0, 2048, 2, 32, False).shape[0] == 0
+
+
+def test_every_pcm_format_to_f64(be, g5):
+    """R1: the fused to_f64 of every ffmpeg-style format, incl. the big-endian-int quirk."""
+    rb = g5["fmt_bytes"]
+    for fmt in fo.PCM_FORMATS:
+        dt = fo.pcm_dtype(fmt)
+        n = rb.size // dt.itemsize
+        raw = np.frombuffer(rb.tobytes(), dt)
+        want = np.asarray(g5[f"to_f64_{fmt}"]).astype(np.float64)
+        if dt.kind == "f":
+            want = np.where(np.isfinite(want), want, 0.0)     # decode scrubs what the payload stored
+        got, am = be.analogue(4, raw, fmt, 1, n, 1, 64, False, raw_be=True)
+        dec = be.digital(4, got, 1, n, 1, 64, False)[0, :, 0]
+        assert np.array_equal(dec, want), fmt
+        if dt.kind != "f" and not dt.isnative:                # and the intended arithmetic without the quirk
+            got, am = be.analogue(4, raw, fmt, 1, n, 1, 64, False, raw_be=False)
+            dec = be.digital(4, got, 1, n, 1, 64, False)[0, :, 0]
+            assert np.array_equal(dec, np.asarray(fo.to_f64(raw, dt, be_int_quirk=False)))
+
+
+def test_golden_g2_frames_through_the_kernels(be, g2):
+    arrs, index = g2
+    step = 7 if be.name == "emu" else 1
+    for c in index[::step]:
+        if c["fmt"] in ("s16be",) and False:
+            continue
+        N, C, bits, le, fmt = c["N"], c["C"], c["bits"], c["le"], c["fmt"]
+        dt = fo.pcm_dtype(fmt)
+        raw = arrs[c["key"] + "_in"]
+        if raw.dtype == np.uint8 and dt.itemsize > 1:
+            raw = np.frombuffer(raw.tobytes(), dt)
+        if DEPTHS_IDX(c["idx"]) != bits:
+            continue                                          # escalated in the reference: host logic, tested apart
+        f64_compute = not fmt.startswith(("f32", "f16"))
+        if c["profile"] == 0 and N * C * (16 if f64_compute else 8) > 160 * 1024:
+            # one frame's channels exceed the 160 KiB LDS of a CU: the core refuses loudly (limits)
+            from frad_python_amd._lib import FradError
+            with pytest.raises(FradError):
+                be.analogue(0, np.ascontiguousarray(raw), fmt, 1, N, C, bits, le)
+            continue
+        pay, am = be.analogue(c["profile"], np.ascontiguousarray(raw), fmt, 1, N, C, bits, le)
+        want = arrs[c["key"] + "_frad"]
+        if c["profile"] == 4:
+            assert np.array_equal(pay[0], want), c["key"]
+        else:
+            m = check_p0_payload(pay[0], want, bits, le, fmt, N)
+            assert m <= 1, c["key"]
+        if c["dec"]:
+            dec = be.digital(c["profile"], want.reshape(1, -1), 1, N, C, bits, le)[0]
+            ref = arrs[c["key"] + "_dec"]
+            if c["profile"] == 4:
+                assert np.array_equal(dec, ref)
+            else:
+                assert np.max(np.abs(dec - ref)) <= 16 * EPS64 * max(np.log2(N), 1) * max(1.0, np.max(np.abs(ref)))
+
+
+def DEPTHS_IDX(i):
+    return fo.DEPTHS[i]
+
+
+def test_golden_g1_vectors(be):
+    g1 = load_json("g1_pack.json")
+    x = np.array(g1["input"])
+    for c in g1["cases"]:
+        pay, am = be.analogue(4, x[:c["n"]].astype("<f8"), "f64le", 1, c["n"], 1, c["bits"], c["le"])
+        assert pay[0].tobytes().hex() == c["hex"]
+        dec = be.digital(4, pay, 1, c["n"], 1, c["bits"], c["le"])
+        assert dec[0].astype("<f8").tobytes().hex() == c["decoded_hex"]
