@@ -1,6 +1,6 @@
 // frad_hip.hip -- C-ABI entry points of libfrad_hip.so (see include/frad_hip.h) and kernel launch
 // logic.  Built with  hipcc --offload-arch=gfx950 -shared -fPIC  (see __graft_entry__.build()).
-#include "frad_kernels.hpp"
+#include "frad_launch.hpp"
 #include "../../include/frad_hip.h"
 
 #include <cmath>
@@ -48,7 +48,6 @@ void unit_neg(long long p, long long q, long double& re, long double& im) {
     re = C; im = -S;
 }
 
-struct Tables { void* tw = nullptr; void* post = nullptr; };
 struct DirectTable { double* ct = nullptr; };
 
 std::mutex g_mu;
@@ -110,7 +109,6 @@ int get_direct(int N, DirectTable& out) {
 }
 
 // launch geometry of the FFT kernels
-struct FastCfg { bool ok = false; int log2m = 0, team = 0, fpb = 0, threads = 0; size_t lds = 0; };
 int team_of(int log2m) {
     switch (log2m) { case 6: return 16; case 7: return 32; case 8: case 9: case 10: return 64;
                      case 11: return 128; case 12: return 256; case 13: return 512; default: return 0; }
@@ -128,13 +126,11 @@ FastCfg fast_cfg(int N, int C, bool f32) {
     if (c.team < 64) { const int w = 64 / c.team; q = w / gcd(C, w); }
     if (q * pft > 1024 || q * pfl > (size_t)kLdsBytes) return c;
     int fpb = q;
-    while ((fpb + q) * pft <= 512 && (size_t)(fpb + q) * pfl <= 80 * 1024) fpb += q;
+    // 256-thread blocks keep the whole register file available to the radix-16 butterflies; two
+    // such blocks (<= 80 KiB of LDS each) share a CU so that one streams while the other computes
+    while ((fpb + q) * pft <= 256 && (size_t)(fpb + q) * pfl <= 80 * 1024) fpb += q;
     c.fpb = fpb; c.threads = (int)(fpb * pft); c.lds = fpb * pfl; c.ok = true;
     return c;
-}
-
-template <typename K> void allow_lds(K kernel, size_t bytes) {
-    if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 int check_common(const void* a, const void* b, long long n_frames, int N, int C, int bits) {
@@ -161,42 +157,10 @@ int launch_p4_pack_lg(int lg, dim3 grid, hipStream_t s, const unsigned char* pcm
     return FRAD_OK;
 }
 
-template <typename T, int LOG2M>
-int launch_fwd_lg(int lg, const FastCfg& c, dim3 grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* am,
-                  const Tables& tb, const Geom& g, int ai, int ao) {
-    const cx<T>* tw = static_cast<const cx<T>*>(tb.tw); const cx<T>* post = static_cast<const cx<T>*>(tb.post);
-#define FRAD_FWD(LGV) do { allow_lds(k_p0_fwd<T, LOG2M, LGV>, c.lds); \
-        hipLaunchKernelGGL((k_p0_fwd<T, LOG2M, LGV>), grid, dim3(c.threads), c.lds, s, pcm, pay, am, tw, post, g, ai, ao); } while (0)
-    if constexpr (sizeof(T) == 4) {
-        if (lg == 1) FRAD_FWD(1); else FRAD_FWD(2);
-    } else {
-        switch (lg) { case 0: FRAD_FWD(0); break; case 1: FRAD_FWD(1); break; case 2: FRAD_FWD(2); break; default: FRAD_FWD(3); break; }
-    }
-#undef FRAD_FWD
-    return FRAD_OK;
-}
-
-template <typename T>
-int launch_fwd(int lg, const FastCfg& c, dim3 grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* am,
-               const Tables& tb, const Geom& g, int ai, int ao) {
-    switch (c.log2m) {
-        case 6: return launch_fwd_lg<T, 6>(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao);
-        case 7: return launch_fwd_lg<T, 7>(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao);
-        case 8: return launch_fwd_lg<T, 8>(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao);
-        case 9: return launch_fwd_lg<T, 9>(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao);
-        case 10: return launch_fwd_lg<T, 10>(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao);
-        case 11: return launch_fwd_lg<T, 11>(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao);
-        case 12: return launch_fwd_lg<T, 12>(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao);
-        default: return launch_fwd_lg<T, 13>(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao);
-    }
-}
-
-int launch_inv(const FastCfg& c, dim3 grid, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb, const Geom& g, int ai) {
-    const cx<double>* tw = static_cast<const cx<double>*>(tb.tw); const cx<double>* post = static_cast<const cx<double>*>(tb.post);
-#define FRAD_INV(L) case L: allow_lds(k_p0_inv<L>, c.lds); hipLaunchKernelGGL((k_p0_inv<L>), grid, dim3(c.threads), c.lds, s, pay, out, tw, post, g, ai); break
-    switch (c.log2m) { FRAD_INV(6); FRAD_INV(7); FRAD_INV(8); FRAD_INV(9); FRAD_INV(10); FRAD_INV(11); FRAD_INV(12); FRAD_INV(13); default: return FRAD_E_UNSUPPORTED; }
-#undef FRAD_INV
-    return FRAD_OK;
+int launch_p0_fwd_f64(int lg, const FastCfg& c, dim3 grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay,
+                      double* am, const Tables& tb, const Geom& g, int ai, int ao) {
+    return c.log2m <= 9 ? launch_p0_fwd_f64_lo(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao)
+                        : launch_p0_fwd_f64_hi(lg, c, grid, s, pcm, pay, am, tb, g, ai, ao);
 }
 
 Geom make_geom(long long n_frames, int N, int C, long long frame_stride, long long payload_stride, int bits, uint32_t flags, int dtype) {
@@ -279,7 +243,7 @@ int frad_p4_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
             default: launch_p4_pack_lg<64>(lg, grid, s, in, out, absmax, g, bpf); break;
         }
     } else {
-        hipLaunchKernelGGL(k_p4_pack_slow, grid, dim3(256), 0, s, in, out, absmax, g, bpf);
+        hipLaunchKernelGGL(k_p4_pack_slow<0>, grid, dim3(256), 0, s, in, out, absmax, g, bpf);
     }
     HIPCHK(hipGetLastError());
     return FRAD_OK;
@@ -310,7 +274,7 @@ int frad_p4_digital(const void* payload, int64_t payload_stride, int64_t n_frame
             default: hipLaunchKernelGGL(k_p4_unpack<64>, grid, dim3(256), 0, s, in, pcm_out, g, bpf); break;
         }
     } else {
-        hipLaunchKernelGGL(k_p4_unpack_slow, grid, dim3(256), 0, s, in, pcm_out, g, bpf);
+        hipLaunchKernelGGL(k_p4_unpack_slow<0>, grid, dim3(256), 0, s, in, pcm_out, g, bpf);
     }
     HIPCHK(hipGetLastError());
     return FRAD_OK;
@@ -338,8 +302,8 @@ int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
         if (absmax) HIPCHK(hipMemsetAsync(absmax, 0, sizeof(double) * (size_t)n_frames, s));
         g.fpb = c.fpb;
         dim3 grid((unsigned)((n_frames + c.fpb - 1) / c.fpb));
-        rc = f32 ? launch_fwd<float>(lg, c, grid, s, in, out, absmax, tb, g, ai, ao)
-                 : launch_fwd<double>(lg, c, grid, s, in, out, absmax, tb, g, ai, ao);
+        rc = f32 ? launch_p0_fwd_f32(lg, c, grid, s, in, out, absmax, tb, g, ai, ao)
+                 : launch_p0_fwd_f64(lg, c, grid, s, in, out, absmax, tb, g, ai, ao);
         if (rc != FRAD_OK) return rc;
     } else {
         const size_t lds = 2 * (size_t)N * C * (f32 ? 4 : 8);
@@ -374,23 +338,18 @@ int frad_p0_digital(const void* payload, int64_t payload_stride, int64_t n_frame
         if (rc != FRAD_OK) return rc;
         g.fpb = c.fpb;
         dim3 grid((unsigned)((n_frames + c.fpb - 1) / c.fpb));
-        rc = launch_inv(c, grid, s, in, pcm_out, tb, g, ai);
+        rc = launch_p0_inv(c, grid, s, in, pcm_out, tb, g, ai);
         if (rc != FRAD_OK) return rc;
     } else {
         const size_t lds = 2 * (size_t)N * C * 8;
         if (lds > (size_t)kLdsBytes || n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
         DirectTable d; rc = get_direct(N, d);
         if (rc != FRAD_OK) return rc;
-        allow_lds(k_p0_inv_direct, lds);
-        hipLaunchKernelGGL(k_p0_inv_direct, dim3((unsigned)n_frames), dim3(256), lds, s, in, pcm_out, d.ct, g, ai);
+        allow_lds(k_p0_inv_direct<0>, lds);
+        hipLaunchKernelGGL(k_p0_inv_direct<0>, dim3((unsigned)n_frames), dim3(256), lds, s, in, pcm_out, d.ct, g, ai);
     }
     HIPCHK(hipGetLastError());
     return FRAD_OK;
 }
-
-int frad_p1_analogue(const void*, int32_t, int64_t, int32_t, int32_t, int64_t, int32_t, int32_t, int32_t, double,
-                     uint32_t, int32_t*, int32_t*, void*) { return FRAD_E_UNSUPPORTED; }
-int frad_p1_digital(const int32_t*, const int32_t*, int64_t, int32_t, int32_t, int32_t, int32_t, double*, void*) { return FRAD_E_UNSUPPORTED; }
-int frad_p1_overlap_add(const double*, int64_t, int32_t, int32_t, int32_t, const double*, double*, double*, void*) { return FRAD_E_UNSUPPORTED; }
 
 }  // extern "C"

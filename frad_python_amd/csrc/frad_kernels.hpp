@@ -123,6 +123,7 @@ __global__ void __launch_bounds__(256) k_p4_pack(const unsigned char* __restrict
 }
 
 // Any alignment / any geometry: one thread per payload byte and per value.
+template <int UNUSED>
 __global__ void __launch_bounds__(256) k_p4_pack_slow(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload,
                                                       double* absmax, Geom g, int bpf) {
     const long long f = blockIdx.x / bpf;
@@ -181,6 +182,7 @@ __global__ void __launch_bounds__(256) k_p4_unpack(const unsigned char* __restri
             dst[i] = code_to_f64(code_from_bytes(src, i, BITS, le), BITS);
 }
 
+template <int UNUSED>
 __global__ void __launch_bounds__(256) k_p4_unpack_slow(const unsigned char* __restrict__ payload, double* __restrict__ out,
                                                         Geom g, int bpf) {
     const long long f = blockIdx.x / bpf;
@@ -381,8 +383,8 @@ __device__ __forceinline__ void store_pcm_f64(unsigned char* smem, double* __res
 // K3/K5  profile 0 encode, N = 2^(LOG2M+1): LDS-resident FFT.
 // block = fpb frames x C channels x TEAM lanes (rounded up to whole waves).
 // =============================================================================================
-template <typename T, int LOG2M, int LG>
-__global__ void __launch_bounds__(1024) k_p0_fwd(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload,
+template <typename T, int LOG2M, int LG, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_p0_fwd(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload,
                                                   double* absmax, const cx<T>* __restrict__ tw, const cx<T>* __restrict__ post,
                                                   Geom g, int aligned_in, int aligned_out) {
     constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM, SLOTS = padded_slots(M);
@@ -406,8 +408,8 @@ __global__ void __launch_bounds__(1024) k_p0_fwd(const unsigned char* __restrict
 // =============================================================================================
 // K4  profile 0 decode (always float64, as the reference widens before idct).
 // =============================================================================================
-template <int LOG2M>
-__global__ void __launch_bounds__(1024) k_p0_inv(const unsigned char* __restrict__ payload, double* __restrict__ out,
+template <int LOG2M, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_p0_inv(const unsigned char* __restrict__ payload, double* __restrict__ out,
                                                   const cx<double>* __restrict__ tw, const cx<double>* __restrict__ post,
                                                   Geom g, int aligned_in) {
     constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM, SLOTS = padded_slots(M);
@@ -458,6 +460,7 @@ __global__ void __launch_bounds__(256) k_p0_fwd_direct(const unsigned char* __re
     pack_out_any<T, false>(reinterpret_cast<unsigned char*>(X), payload, absmax, g, f0, 1, N, aligned_out != 0);
 }
 
+template <int UNUSED>
 __global__ void __launch_bounds__(256) k_p0_inv_direct(const unsigned char* __restrict__ payload, double* __restrict__ out,
                                                        const double* __restrict__ ct, Geom g, int aligned_in) {
     FRAD_DYN_SMEM(smem);

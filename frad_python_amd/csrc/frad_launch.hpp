@@ -1,0 +1,33 @@
+// frad_launch.hpp -- host-side launch interface between the C-ABI translation unit (frad_hip.hip)
+// and the translation units that instantiate the FFT kernels (frad_p0_*.hip).  The kernels are
+// split over several objects only so that hipcc can build them in parallel.
+#pragma once
+#include "frad_kernels.hpp"
+
+namespace frad {
+
+struct Tables { void* tw = nullptr; void* post = nullptr; };
+
+// launch geometry of the LDS-resident FFT kernels
+struct FastCfg {
+    bool ok = false;
+    int log2m = 0, team = 0, fpb = 0, threads = 0;
+    size_t lds = 0;
+};
+
+template <typename K> inline void allow_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// each returns 0 or FRAD_E_UNSUPPORTED (-2) when that (log2m, lg) is not built
+int launch_p0_fwd_f64_lo(int lg, const FastCfg& c, dim3 grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay,
+                         double* absmax, const Tables& tb, const Geom& g, int aligned_in, int aligned_out);
+int launch_p0_fwd_f64_hi(int lg, const FastCfg& c, dim3 grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay,
+                         double* absmax, const Tables& tb, const Geom& g, int aligned_in, int aligned_out);
+int launch_p0_fwd_f32(int lg, const FastCfg& c, dim3 grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay,
+                      double* absmax, const Tables& tb, const Geom& g, int aligned_in, int aligned_out);
+int launch_p0_inv(const FastCfg& c, dim3 grid, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb,
+                  const Geom& g, int aligned_in);
+
+}  // namespace frad

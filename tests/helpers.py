@@ -19,10 +19,8 @@ CSRC = os.path.join(ROOT, "frad_python_amd", "csrc")
 
 
 def build_emulator() -> str:
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
-    srcs += [os.path.join(EMU_DIR, "hip_emu.hpp"), os.path.join(ROOT, "include", "frad_hip.h")]
-    if not os.path.exists(EMU_LIB) or any(os.path.getmtime(s) > os.path.getmtime(EMU_LIB) for s in srcs):
-        subprocess.run([os.path.join(EMU_DIR, "build_emu.sh")], check=True)
+    """make emu (g++, thread-per-lane interpreter of the same kernel source); no-op when current."""
+    subprocess.run(["make", "-j8", "emu"], check=True, cwd=CSRC, stdout=subprocess.DEVNULL)
     return EMU_LIB
 
 

@@ -33,6 +33,17 @@ def _sizes(be, emu, gpu):
     return emu if be.name == "emu" else gpu
 
 
+def fits_lds(N, C, fmt):
+    """Does one frame (all channels) fit the 160 KiB LDS of a CU?  FFT path: C padded buffers of
+    N/2 complex values; direct path (other N): x and X, 2*N*C reals."""
+    size = 4 if fmt.startswith(("f32", "f16")) else 8
+    pow2 = N >= 128 and N <= 16384 and (N & (N - 1)) == 0
+    if pow2:
+        M = N // 2
+        return C * (M + M // 16 + 1) * 2 * size <= 160 * 1024
+    return 2 * N * C * size <= 160 * 1024
+
+
 def check_p0_payload(got, want, bits, le, fmt, N):
     """Payload of one frame against the oracle's, per the tolerance contract."""
     f32 = fmt.startswith(("f32", "f16"))
@@ -91,6 +102,8 @@ def test_p0_fft_sizes(be, fmt):
                     [(2048, 2, 9), (128, 1, 5), (256, 3, 4), (512, 2, 4), (1024, 1, 3), (4096, 2, 3), (4096, 8, 3),
                      (8192, 1, 2), (16384, 1, 2), (2048, 8, 3), (128, 5, 3), (2048, 1, 5)])
     for (N, C, F) in shapes:
+        if not fits_lds(N, C, fmt):
+            continue                                          # beyond one CU's LDS in this precision (limits)
         x = rng.uniform(-1, 1, (F * N, C))
         x[:N] = synth.harmonic_mix(N, C, 48000, seed=N)          # one realistic frame, the rest full-scale noise
         raw = synth.to_pcm(x, fmt)
@@ -213,8 +226,7 @@ def test_golden_g2_frames_through_the_kernels(be, g2):
             raw = np.frombuffer(raw.tobytes(), dt)
         if DEPTHS_IDX(c["idx"]) != bits:
             continue                                          # escalated in the reference: host logic, tested apart
-        f64_compute = not fmt.startswith(("f32", "f16"))
-        if c["profile"] == 0 and N * C * (16 if f64_compute else 8) > 160 * 1024:
+        if c["profile"] == 0 and not fits_lds(N, C, fmt):
             # one frame's channels exceed the 160 KiB LDS of a CU: the core refuses loudly (limits)
             from frad_python_amd._lib import FradError
             with pytest.raises(FradError):
