@@ -27,10 +27,16 @@ template <bool INV, typename T> __device__ __forceinline__ cx<T> mul_mi(cx<T> a)
     if constexpr (INV) return {-a.y, a.x}; else return {a.y, -a.x};
 }
 
-// LDS layout: one pad slot after every 16 complex slots.  Keeps both the lane-contiguous reads
-// (index b + j*M/R) and the lane-strided Stockham writes (stride R slots) off the same banks.
-__device__ __forceinline__ int phys(int i) { return i + (i >> 4); }
-__host__ __device__ constexpr int padded_slots(int m) { return m + (m >> 4) + 1; }
+// LDS layout: XOR swizzle, no padding.  Slot i lives at i ^ ((i >> SH) & mask), SH = log2 of the
+// plan's first radix, mask = 7 for 16-byte slots (ds_write_b128 serves 8 lanes x 16 B per pass over
+// 32 banks) and 15 for 8-byte slots.  Lane-contiguous accesses stay inside aligned 16-slot rows
+// (conflict-free for every ds_read/ds_write lane group) and the first pass's lane-strided Stockham
+// scatter (stride R slots) is spread over all banks instead of hitting one.
+template <typename T, int SH> __device__ __forceinline__ int phys(int i) {
+    if constexpr (SH < 0) return i;
+    else return i ^ ((i >> SH) & (sizeof(cx<T>) == 16 ? 7 : 15));
+}
+__host__ __device__ constexpr int padded_slots(int m) { return m; }
 
 // constants (correctly rounded)
 template <typename T> struct K {
@@ -119,16 +125,28 @@ template <int TEAM> __device__ __forceinline__ void team_sync() {
 
 // One Stockham pass of radix R with accumulated stride NS over the M-point array `buf`
 // (padded layout).  `t` = lane index inside the team.  `tw` = W_M^k table, k in [0, M).
-template <typename T, int M, int TEAM, int R, int NS, bool INV>
+template <typename T, int M, int TEAM, int R, int NS, bool INV, int SH>
 __device__ __forceinline__ void fft_pass(cx<T>* buf, int t, const cx<T>* __restrict__ tw) {
     constexpr int NB = M / R / TEAM;            // butterflies per lane
     static_assert(NB >= 1 && NB * R * TEAM == M, "pass geometry");
     cx<T> v[NB][R];
+    cx<T> w[NB][R];
+    __builtin_amdgcn_sched_barrier(0);          // keep this pass's loads out of the previous pass's registers
+    // twiddles first: they come from L2 and depend on the lane only, so their latency overlaps the
+    // LDS reads below instead of following them
+    if constexpr (NS > 1) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int k = (t + nb * TEAM) & (NS - 1);
+#pragma unroll
+            for (int j = 1; j < R; ++j) w[nb][j] = tw[j * k * (M / (NS * R))];
+        }
+    }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int b = t + nb * TEAM;
 #pragma unroll
-        for (int j = 0; j < R; ++j) v[nb][j] = buf[phys(b + j * (M / R))];
+        for (int j = 0; j < R; ++j) v[nb][j] = buf[phys<T, SH>(b + j * (M / R))];
     }
     team_sync<TEAM>();
 #pragma unroll
@@ -138,58 +156,58 @@ __device__ __forceinline__ void fft_pass(cx<T>* buf, int t, const cx<T>* __restr
         if constexpr (NS > 1) {
 #pragma unroll
             for (int j = 1; j < R; ++j) {
-                cx<T> w = tw[j * k * (M / (NS * R))];
-                if constexpr (INV) w.y = -w.y;
-                v[nb][j] = cmul(v[nb][j], w);
+                cx<T> ww = w[nb][j];
+                if constexpr (INV) ww.y = -ww.y;
+                v[nb][j] = cmul(v[nb][j], ww);
             }
         }
         dft<R, INV>(v[nb]);
         const int base = (b - k) * R + k;
 #pragma unroll
-        for (int j = 0; j < R; ++j) buf[phys(base + j * NS)] = v[nb][j];
+        for (int j = 0; j < R; ++j) buf[phys<T, SH>(base + j * NS)] = v[nb][j];
     }
     team_sync<TEAM>();
 }
 
 // Pass schedules.  P = points per lane = max radix, TEAM = M / P lanes per channel-frame.
 template <int LOG2M> struct Plan;
-template <> struct Plan<6>  { static constexpr int TEAM = 16;  };   // M = 64   : 4 4 4
-template <> struct Plan<7>  { static constexpr int TEAM = 32;  };   // M = 128  : 4 4 4 2
-template <> struct Plan<8>  { static constexpr int TEAM = 64;  };   // M = 256  : 4 4 4 4
-template <> struct Plan<9>  { static constexpr int TEAM = 64;  };   // M = 512  : 8 8 8
-template <> struct Plan<10> { static constexpr int TEAM = 64;  };   // M = 1024 : 16 16 4
-template <> struct Plan<11> { static constexpr int TEAM = 128; };   // M = 2048 : 16 16 8
-template <> struct Plan<12> { static constexpr int TEAM = 256; };   // M = 4096 : 16 16 16
-template <> struct Plan<13> { static constexpr int TEAM = 512; };   // M = 8192 : 16 16 16 2
+template <> struct Plan<6>  { static constexpr int TEAM = 16,  SH = 2; };   // M = 64   : 4 4 4
+template <> struct Plan<7>  { static constexpr int TEAM = 32,  SH = 2; };   // M = 128  : 4 4 4 2
+template <> struct Plan<8>  { static constexpr int TEAM = 64,  SH = 2; };   // M = 256  : 4 4 4 4
+template <> struct Plan<9>  { static constexpr int TEAM = 64,  SH = 3; };   // M = 512  : 8 8 8
+template <> struct Plan<10> { static constexpr int TEAM = 64,  SH = 4; };   // M = 1024 : 16 16 4
+template <> struct Plan<11> { static constexpr int TEAM = 128, SH = 4; };   // M = 2048 : 16 16 8
+template <> struct Plan<12> { static constexpr int TEAM = 256, SH = 4; };   // M = 4096 : 16 16 16
+template <> struct Plan<13> { static constexpr int TEAM = 512, SH = 4; };   // M = 8192 : 16 16 16 2
 
 template <typename T, int LOG2M, bool INV>
 __device__ __forceinline__ void fft_team(cx<T>* buf, int t, const cx<T>* __restrict__ tw) {
-    constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM;
+    constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM, SH = Plan<LOG2M>::SH;
     if constexpr (LOG2M == 6) {
-        fft_pass<T, M, TEAM, 4, 1, INV>(buf, t, tw); fft_pass<T, M, TEAM, 4, 4, INV>(buf, t, tw);
-        fft_pass<T, M, TEAM, 4, 16, INV>(buf, t, tw);
+        fft_pass<T, M, TEAM, 4, 1, INV, SH>(buf, t, tw); fft_pass<T, M, TEAM, 4, 4, INV, SH>(buf, t, tw);
+        fft_pass<T, M, TEAM, 4, 16, INV, SH>(buf, t, tw);
     } else if constexpr (LOG2M == 7) {
-        fft_pass<T, M, TEAM, 4, 1, INV>(buf, t, tw); fft_pass<T, M, TEAM, 4, 4, INV>(buf, t, tw);
-        fft_pass<T, M, TEAM, 4, 16, INV>(buf, t, tw); fft_pass<T, M, TEAM, 2, 64, INV>(buf, t, tw);
+        fft_pass<T, M, TEAM, 4, 1, INV, SH>(buf, t, tw); fft_pass<T, M, TEAM, 4, 4, INV, SH>(buf, t, tw);
+        fft_pass<T, M, TEAM, 4, 16, INV, SH>(buf, t, tw); fft_pass<T, M, TEAM, 2, 64, INV, SH>(buf, t, tw);
     } else if constexpr (LOG2M == 8) {
-        fft_pass<T, M, TEAM, 4, 1, INV>(buf, t, tw); fft_pass<T, M, TEAM, 4, 4, INV>(buf, t, tw);
-        fft_pass<T, M, TEAM, 4, 16, INV>(buf, t, tw); fft_pass<T, M, TEAM, 4, 64, INV>(buf, t, tw);
+        fft_pass<T, M, TEAM, 4, 1, INV, SH>(buf, t, tw); fft_pass<T, M, TEAM, 4, 4, INV, SH>(buf, t, tw);
+        fft_pass<T, M, TEAM, 4, 16, INV, SH>(buf, t, tw); fft_pass<T, M, TEAM, 4, 64, INV, SH>(buf, t, tw);
     } else if constexpr (LOG2M == 9) {
-        fft_pass<T, M, TEAM, 8, 1, INV>(buf, t, tw); fft_pass<T, M, TEAM, 8, 8, INV>(buf, t, tw);
-        fft_pass<T, M, TEAM, 8, 64, INV>(buf, t, tw);
+        fft_pass<T, M, TEAM, 8, 1, INV, SH>(buf, t, tw); fft_pass<T, M, TEAM, 8, 8, INV, SH>(buf, t, tw);
+        fft_pass<T, M, TEAM, 8, 64, INV, SH>(buf, t, tw);
     } else if constexpr (LOG2M == 10) {
-        fft_pass<T, M, TEAM, 16, 1, INV>(buf, t, tw); fft_pass<T, M, TEAM, 16, 16, INV>(buf, t, tw);
-        fft_pass<T, M, TEAM, 4, 256, INV>(buf, t, tw);
+        fft_pass<T, M, TEAM, 16, 1, INV, SH>(buf, t, tw); fft_pass<T, M, TEAM, 16, 16, INV, SH>(buf, t, tw);
+        fft_pass<T, M, TEAM, 4, 256, INV, SH>(buf, t, tw);
     } else if constexpr (LOG2M == 11) {
-        fft_pass<T, M, TEAM, 16, 1, INV>(buf, t, tw); fft_pass<T, M, TEAM, 16, 16, INV>(buf, t, tw);
-        fft_pass<T, M, TEAM, 8, 256, INV>(buf, t, tw);
+        fft_pass<T, M, TEAM, 16, 1, INV, SH>(buf, t, tw); fft_pass<T, M, TEAM, 16, 16, INV, SH>(buf, t, tw);
+        fft_pass<T, M, TEAM, 8, 256, INV, SH>(buf, t, tw);
     } else if constexpr (LOG2M == 12) {
-        fft_pass<T, M, TEAM, 16, 1, INV>(buf, t, tw); fft_pass<T, M, TEAM, 16, 16, INV>(buf, t, tw);
-        fft_pass<T, M, TEAM, 16, 256, INV>(buf, t, tw);
+        fft_pass<T, M, TEAM, 16, 1, INV, SH>(buf, t, tw); fft_pass<T, M, TEAM, 16, 16, INV, SH>(buf, t, tw);
+        fft_pass<T, M, TEAM, 16, 256, INV, SH>(buf, t, tw);
     } else {
         static_assert(LOG2M == 13, "plan");
-        fft_pass<T, M, TEAM, 16, 1, INV>(buf, t, tw); fft_pass<T, M, TEAM, 16, 16, INV>(buf, t, tw);
-        fft_pass<T, M, TEAM, 16, 256, INV>(buf, t, tw); fft_pass<T, M, TEAM, 2, 4096, INV>(buf, t, tw);
+        fft_pass<T, M, TEAM, 16, 1, INV, SH>(buf, t, tw); fft_pass<T, M, TEAM, 16, 16, INV, SH>(buf, t, tw);
+        fft_pass<T, M, TEAM, 16, 256, INV, SH>(buf, t, tw); fft_pass<T, M, TEAM, 2, 4096, INV, SH>(buf, t, tw);
     }
 }
 
@@ -197,8 +215,8 @@ __device__ __forceinline__ void fft_team(cx<T>* buf, int t, const cx<T>* __restr
 // DCT-II <-> packed-FFT glue.  Real slot r of a channel buffer lives in complex slot r>>1,
 // component r&1 (same padded layout), so the N reals X[k] overlay the M complex points.
 // ---------------------------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ T& real_slot(cx<T>* buf, int r) {
-    return reinterpret_cast<T*>(buf + phys(r >> 1))[r & 1];
+template <typename T, int SH> __device__ __forceinline__ T& real_slot(cx<T>* buf, int r) {
+    return reinterpret_cast<T*>(buf + phys<T, SH>(r >> 1))[r & 1];
 }
 // position of time sample n in Makhoul's permuted sequence v (v[i] = x[2i], v[N-1-i] = x[2i+1])
 __device__ __forceinline__ int makhoul(int n, int N) { return (n & 1) ? N - 1 - (n >> 1) : (n >> 1); }
@@ -208,16 +226,17 @@ __device__ __forceinline__ int makhoul(int n, int N) { return (n & 1) ? N - 1 - 
 // forward: Z (FFT of the packed sequence) -> X[k] = (1/N) sum x[n] cos(pi k (2n+1) / 2N), in place.
 template <typename T, int LOG2M>
 __device__ __forceinline__ void dct_post(cx<T>* buf, int t, const cx<T>* __restrict__ post) {
-    constexpr int M = 1 << LOG2M, N = 2 * M, TEAM = Plan<LOG2M>::TEAM;
+    constexpr int M = 1 << LOG2M, N = 2 * M, TEAM = Plan<LOG2M>::TEAM, SH = Plan<LOG2M>::SH;
     constexpr int PP = (M / 2) / TEAM;         // pairs per lane (pair M/2 goes to lane 0 on top)
     constexpr T sc = (T)1 / (T)(2 * N);
     constexpr T sc2 = K<T>::s2 / (T)(2 * N);
     cx<T> S[PP + 1], D[PP + 1];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i <= PP; ++i) {
         const int k = (i < PP) ? t + i * TEAM : M / 2;
         if (i == PP && t != 0) continue;
-        const cx<T> zk = buf[phys(k)], zp = conj(buf[phys((M - k) & (M - 1))]);
+        const cx<T> zk = buf[phys<T, SH>(k)], zp = conj(buf[phys<T, SH>((M - k) & (M - 1))]);
         const cx<T> p = cmul(zk + zp, post[2 * k]), q = cmul(zk - zp, post[2 * k + 1]);
         S[i] = p + q; D[i] = p - q;
     }
@@ -226,11 +245,11 @@ __device__ __forceinline__ void dct_post(cx<T>* buf, int t, const cx<T>* __restr
     for (int i = 0; i <= PP; ++i) {
         const int k = (i < PP) ? t + i * TEAM : M / 2;
         if (i == PP && t != 0) continue;
-        real_slot(buf, k) = S[i].x * sc;
-        if (k > 0) real_slot(buf, N - k) = -S[i].y * sc;
+        real_slot<T, SH>(buf, k) = S[i].x * sc;
+        if (k > 0) real_slot<T, SH>(buf, N - k) = -S[i].y * sc;
         if (k < M / 2) {
-            real_slot(buf, M - k) = (D[i].x - D[i].y) * sc2;
-            if (k > 0) real_slot(buf, M + k) = (D[i].x + D[i].y) * sc2;
+            real_slot<T, SH>(buf, M - k) = (D[i].x - D[i].y) * sc2;
+            if (k > 0) real_slot<T, SH>(buf, M + k) = (D[i].x + D[i].y) * sc2;
         }
     }
     team_sync<TEAM>();
@@ -240,16 +259,17 @@ __device__ __forceinline__ void dct_post(cx<T>* buf, int t, const cx<T>* __restr
 // the unscaled inverse FFT returns the packed time sequence.
 template <typename T, int LOG2M>
 __device__ __forceinline__ void dct_pre_inverse(cx<T>* buf, int t, const cx<T>* __restrict__ post) {
-    constexpr int M = 1 << LOG2M, N = 2 * M, TEAM = Plan<LOG2M>::TEAM;
+    constexpr int M = 1 << LOG2M, N = 2 * M, TEAM = Plan<LOG2M>::TEAM, SH = Plan<LOG2M>::SH;
     constexpr int PP = (M / 2) / TEAM;
     cx<T> A[PP + 1], B[PP + 1];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i <= PP; ++i) {
         const int k = (i < PP) ? t + i * TEAM : M / 2;
         if (i == PP && t != 0) continue;
-        const T xk = real_slot(buf, k);
-        const T xnk = k > 0 ? real_slot(buf, N - k) : (T)0;
-        const T a = real_slot(buf, M - k), b = real_slot(buf, k > 0 ? M + k : M);
+        const T xk = real_slot<T, SH>(buf, k);
+        const T xnk = k > 0 ? real_slot<T, SH>(buf, N - k) : (T)0;
+        const T a = real_slot<T, SH>(buf, M - k), b = real_slot<T, SH>(buf, k > 0 ? M + k : M);
         const cx<T> u = {xk, -xnk};
         const cx<T> s = {(a + b) * K<T>::s2, (b - a) * K<T>::s2};
         A[i] = cmul(u + s, conj(post[2 * k]));
@@ -260,8 +280,8 @@ __device__ __forceinline__ void dct_pre_inverse(cx<T>* buf, int t, const cx<T>* 
     for (int i = 0; i <= PP; ++i) {
         const int k = (i < PP) ? t + i * TEAM : M / 2;
         if (i == PP && t != 0) continue;
-        buf[phys(k)] = A[i] + B[i];
-        if (k > 0 && k < M / 2) buf[phys(M - k)] = conj(A[i] - B[i]);
+        buf[phys<T, SH>(k)] = A[i] + B[i];
+        if (k > 0 && k < M / 2) buf[phys<T, SH>(M - k)] = conj(A[i] - B[i]);
     }
     team_sync<TEAM>();
 }

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -124,12 +125,26 @@ FastCfg fast_cfg(int N, int C, bool f32) {
     const size_t pfl = per_cf * (size_t)C;
     int q = 1;
     if (c.team < 64) { const int w = 64 / c.team; q = w / gcd(C, w); }
-    if (q * pft > 1024 || q * pfl > (size_t)kLdsBytes) return c;
+    if (q * pft > 1024 || q * pfl > (size_t)kLdsBytes) {
+        // one frame's channels exceed a CU: transform `cg` channels per pass (per-value I/O)
+        if (c.team < 64) return c;
+        int cg = C;
+        while (cg > 1 && ((long long)cg * c.team > 1024 || (size_t)cg * per_cf > (size_t)kLdsBytes)) --cg;
+        if ((long long)cg * c.team > 1024 || (size_t)cg * per_cf > (size_t)kLdsBytes) return c;
+        if (cg > 1 && (cg & 1)) --cg;                       // even groups keep 12-bit pairs together
+        c.cg = cg; c.fpb = 1; c.threads = cg * c.team; c.lds = (size_t)cg * per_cf; c.ok = true;
+        return c;
+    }
     int fpb = q;
     // 256-thread blocks keep the whole register file available to the radix-16 butterflies; two
     // such blocks (<= 80 KiB of LDS each) share a CU so that one streams while the other computes
     while ((fpb + q) * pft <= 256 && (size_t)(fpb + q) * pfl <= 80 * 1024) fpb += q;
-    c.fpb = fpb; c.threads = (int)(fpb * pft); c.lds = fpb * pfl; c.ok = true;
+    c.cg = C; c.fpb = fpb; c.threads = (int)(fpb * pft); c.lds = fpb * pfl; c.ok = true;
+    if (const char* e = getenv("FRAD_TUNE_FPB")) {          // tuning knobs for experiments (not part of the ABI)
+        const int v = atoi(e);
+        if (v >= q && v % q == 0 && v * pft <= 1024 && (size_t)v * pfl <= (size_t)kLdsBytes) { c.fpb = v; c.threads = (int)(v * pft); c.lds = v * pfl; }
+    }
+    if (const char* e = getenv("FRAD_TUNE_LDS_PAD")) c.lds += (size_t)atoi(e);
     return c;
 }
 
@@ -167,7 +182,7 @@ Geom make_geom(long long n_frames, int N, int C, long long frame_stride, long lo
     Geom g{};
     g.n_frames = n_frames; g.frame_stride = frame_stride; g.payload_stride = payload_stride;
     g.N = N; g.C = C; g.bits = bits; g.le = (flags & FRAD_LITTLE_ENDIAN) ? 1 : 0; g.dtype = dtype;
-    g.raw_be = (flags & FRAD_RAW_BE_INTS) ? 1 : 0; g.fpb = 1; g.n_valid = N;
+    g.raw_be = (flags & FRAD_RAW_BE_INTS) ? 1 : 0; g.fpb = 1; g.n_valid = N; g.cg = C; g.in_mode = 0; g.cc_fast = 0;
     return g;
 }
 
@@ -300,7 +315,13 @@ int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
         Tables tb; rc = get_tables(c.log2m, f32, tb);
         if (rc != FRAD_OK) return rc;
         if (absmax) HIPCHK(hipMemsetAsync(absmax, 0, sizeof(double) * (size_t)n_frames, s));
-        g.fpb = c.fpb;
+        if (c.cg < C && bits == 12 && ((C & 1) || (c.cg & 1))) return FRAD_E_UNSUPPORTED;
+        g.fpb = c.fpb; g.cg = c.cg;
+        if (c.cg == C && ai) {                               // quad stage-in needs whole 16-byte rows / row groups
+            const int rb = C << lg;
+            g.in_mode = (rb <= 4 && 16 % rb == 0) ? 1 : rb == 8 ? 2 : rb % 16 == 0 ? 3 : 0;
+        }
+        if (c.cg == C && ao && C <= 2 && ((long long)N * C) % 32 == 0) g.cc_fast = C;
         dim3 grid((unsigned)((n_frames + c.fpb - 1) / c.fpb));
         rc = f32 ? launch_p0_fwd_f32(lg, c, grid, s, in, out, absmax, tb, g, ai, ao)
                  : launch_p0_fwd_f64(lg, c, grid, s, in, out, absmax, tb, g, ai, ao);
@@ -336,7 +357,10 @@ int frad_p0_digital(const void* payload, int64_t payload_stride, int64_t n_frame
     if (c.ok) {
         Tables tb; rc = get_tables(c.log2m, false, tb);
         if (rc != FRAD_OK) return rc;
-        g.fpb = c.fpb;
+        if (c.cg < C && bits == 12 && ((C & 1) || (c.cg & 1))) return FRAD_E_UNSUPPORTED;
+        g.fpb = c.fpb; g.cg = c.cg;
+        if (c.cg == C && ai && C <= 2 && ((long long)N * C) % 32 == 0) g.cc_fast = C;
+        if (c.cg == C && C <= 2 && aligned16(pcm_out)) g.in_mode = C;      // decode: quad store for C = 1 / 2
         dim3 grid((unsigned)((n_frames + c.fpb - 1) / c.fpb));
         rc = launch_p0_inv(c, grid, s, in, pcm_out, tb, g, ai);
         if (rc != FRAD_OK) return rc;

@@ -13,6 +13,12 @@
 #include "frad_common.hpp"
 #include "frad_fft.hpp"
 
+#ifndef FRAD_NOINLINE
+// Stage functions are real calls: each gets its own register allocation, so the rarely used pack
+// formats cannot inflate the FFT core's VGPR budget (occupancy: two 256-thread blocks per CU).
+#define FRAD_NOINLINE __attribute__((noinline))
+#endif
+
 namespace frad {
 
 struct Geom {
@@ -26,6 +32,11 @@ struct Geom {
     int raw_be;                 // reference quirk: big-endian ints are not normalised
     int fpb;                    // frames per block (p0 kernels)
     int n_valid;                // sample-frames actually read per frame (<= N, rest zero; profile 1)
+    int cg;                     // channels transformed per pass; < C only when one frame's channels
+                                // exceed a CU's LDS (then fpb == 1 and I/O is per value)
+    int in_mode;                // FFT kernels, PCM side: 0 = per element, 1/2/3 = quad stage-in (row bytes
+                                // divide 16 / equal 8 / multiple of 16), see stage_in_quads
+    int cc_fast;                // FFT kernels, payload side: 1 or 2 = pairwise 16-byte LDS path for C = 1 / 2
 };
 
 __device__ __forceinline__ bool dtype_is_f32_class(int code) { return (code >> 3) == 2 && ((code >> 1) & 3) <= 2; }
@@ -202,17 +213,20 @@ __global__ void __launch_bounds__(256) k_p4_unpack_slow(const unsigned char* __r
 // =============================================================================================
 
 // value of real slot r of channel-frame cf
-template <typename T, bool PADDED>
+// SH >= 0: swizzled complex layout of the FFT kernels (SH = Plan<LOG2M>::SH); SH < 0: plain reals.
+template <typename T, int SH>
 __device__ __forceinline__ T& xslot(unsigned char* smem, int cf, int slots, int r) {
-    if constexpr (PADDED) return real_slot(reinterpret_cast<cx<T>*>(smem) + (long long)cf * slots, r);
+    if constexpr (SH >= 0) return real_slot<T, SH>(reinterpret_cast<cx<T>*>(smem) + (long long)cf * slots, r);
     else return reinterpret_cast<T*>(smem)[(long long)cf * slots + r];
 }
 
 // Stage-in (encode): interleaved PCM of the block's frames -> T in LDS.  PERMUTE applies Makhoul's
 // even/odd permutation (FFT kernels); the direct kernels keep time order.
-template <typename T, int LG, bool PADDED, bool PERMUTE>
-__device__ __forceinline__ void stage_in_pcm(const unsigned char* __restrict__ pcm, unsigned char* smem, const Geom& g,
+template <typename T, int LG, int SH, bool PERMUTE>
+__device__ FRAD_NOINLINE void stage_in_pcm(const unsigned char* __restrict__ pcm, int smem_off, const Geom& g,
                                              long long f0, int nfl, int slots, bool aligned) {
+    FRAD_DYN_SMEM(smem_base_);
+    unsigned char* smem = smem_base_ + smem_off;
     const int N = g.N, C = g.C, NC = N * C;
     const int nv = g.n_valid * C;                     // elements actually present per frame
     if (aligned) {
@@ -240,7 +254,7 @@ __device__ __forceinline__ void stage_in_pcm(const unsigned char* __restrict__ p
                 const int e = e0 + i;
                 if (e < NC) {
                     const T v = e < nv ? cvt_pcm<T>(word_elem<LG>(w, i), g.dtype, g.raw_be) : (T)0;
-                    xslot<T, PADDED>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n) = v;
+                    xslot<T, SH>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n) = v;
                 }
                 if (++c == C) { c = 0; ++n; }
             }
@@ -251,14 +265,234 @@ __device__ __forceinline__ void stage_in_pcm(const unsigned char* __restrict__ p
             const int n = e / C, c = e - n * C;
             const unsigned char* src = pcm + (((f0 + fl) * g.frame_stride * C) << LG);
             const T v = e < nv ? cvt_pcm<T>(load_raw(src + ((long long)e << LG), LG), g.dtype, g.raw_be) : (T)0;
-            xslot<T, PADDED>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n) = v;
+            xslot<T, SH>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n) = v;
+        }
+    }
+}
+
+// Quad stage-in (FFT kernels): four consecutive sample-frames 4q..4q+3 of one channel are exactly
+// the two packed points z[q] = (x[4q], x[4q+2]) and z[M-1-q] = (x[4q+3], x[4q+1]) of Makhoul's
+// permutation, so every LDS write is one whole complex slot (16 B in float64), lane-contiguous and
+// conflict-free, instead of four scattered 8-byte writes.  Requires 16-byte aligned frames,
+// N % 4 == 0 and a row size (C * itemsize) that tiles 16 bytes: mode 1 = row divides 16 (>= 4 rows
+// per 16-byte load, LC = log2 C), mode 2 = row of 8 bytes, mode 3 = row a multiple of 16 bytes.
+template <typename T, int LG, int SH, int LC>
+__device__ __forceinline__ void stage_in_quads_small(const unsigned char* __restrict__ pcm, unsigned char* smem, const Geom& g,
+                                                     long long f0, int nfl, int slots) {
+    constexpr int EPC = 16 >> LG, C = 1 << LC, ROWS = EPC / C, GPC = ROWS / 4;
+    static_assert(GPC >= 1, "row must divide 4 rows into 16 bytes");
+    const int M = g.N >> 1;
+    const int chunks = (g.N * C) / EPC;
+    for (int q = threadIdx.x; q < nfl * chunks; q += blockDim.x) {
+        const int fl = q / chunks, ch = q - fl * chunks;
+        const unsigned char* src = pcm + (((f0 + fl) * g.frame_stride * C) << LG);
+        uint32_t w[4];
+        load_words<4>(src + (long long)ch * 16, w);
+#pragma unroll
+        for (int gi = 0; gi < GPC; ++gi) {
+            const int zq = ch * GPC + gi;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                cx<T>* buf = reinterpret_cast<cx<T>*>(smem) + (long long)(fl * C + c) * slots;
+                T e[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = cvt_pcm<T>(word_elem<LG>(w, (gi * 4 + i) * C + c), g.dtype, g.raw_be);
+                buf[phys<T, SH>(zq)] = cx<T>{e[0], e[2]};
+                buf[phys<T, SH>(M - 1 - zq)] = cx<T>{e[3], e[1]};
+            }
+        }
+    }
+}
+
+template <typename T, int LG, int SH>
+__device__ FRAD_NOINLINE void stage_in_quads(const unsigned char* __restrict__ pcm, int smem_off, const Geom& g,
+                                               long long f0, int nfl, int slots) {
+    FRAD_DYN_SMEM(smem_base_);
+    unsigned char* smem = smem_base_ + smem_off;
+    const int M = g.N >> 1, C = g.C;
+    if (g.in_mode == 1) {
+        if constexpr (LG <= 2) {
+            const int rb = C << LG;
+            if (rb == 1) { if constexpr (LG == 0) stage_in_quads_small<T, LG, SH, 0>(pcm, smem, g, f0, nfl, slots); }
+            else if (rb == 2) { if constexpr (LG <= 1) stage_in_quads_small<T, LG, SH, 1 - LG>(pcm, smem, g, f0, nfl, slots); }
+            else { stage_in_quads_small<T, LG, SH, 2 - LG>(pcm, smem, g, f0, nfl, slots); }
+        }
+    } else if (g.in_mode == 2) {                         // row = 8 bytes: C = 8 >> LG, a quad = 32 contiguous bytes
+        constexpr int CC = 8 >> LG;
+        const int quads = g.N / 4;
+        for (int q = threadIdx.x; q < nfl * quads; q += blockDim.x) {
+            const int fl = q / quads, zq = q - fl * quads;
+            const unsigned char* src = pcm + (((f0 + fl) * g.frame_stride * CC) << LG);
+            uint32_t w[8];
+            load_words<8>(src + (long long)zq * 32, w);
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                cx<T>* buf = reinterpret_cast<cx<T>*>(smem) + (long long)(fl * CC + c) * slots;
+                T e[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) e[i] = cvt_pcm<T>(word_elem<LG>(w, i * CC + c), g.dtype, g.raw_be);
+                buf[phys<T, SH>(zq)] = cx<T>{e[0], e[2]};
+                buf[phys<T, SH>(M - 1 - zq)] = cx<T>{e[3], e[1]};
+            }
+        }
+    } else {                                             // row a multiple of 16 bytes: (quad, 16-byte column slab)
+        constexpr int EPC = 16 >> LG;
+        const int slabs = (C << LG) / 16, quads = g.N / 4;
+        const long long rowb = (long long)C << LG;
+        for (int q = threadIdx.x; q < nfl * quads * slabs; q += blockDim.x) {
+            const int fl = q / (quads * slabs), r = q - fl * quads * slabs;
+            const int zq = r / slabs, sl = r - zq * slabs;
+            const unsigned char* src = pcm + (((f0 + fl) * g.frame_stride * C) << LG) + (long long)zq * 4 * rowb + sl * 16;
+            uint32_t w[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) load_words<4>(src + i * rowb, w[i]);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                cx<T>* buf = reinterpret_cast<cx<T>*>(smem) + (long long)(fl * C + sl * EPC + e) * slots;
+                T v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = cvt_pcm<T>(word_elem<LG>(w[i], e), g.dtype, g.raw_be);
+                buf[phys<T, SH>(zq)] = cx<T>{v[0], v[2]};
+                buf[phys<T, SH>(M - 1 - zq)] = cx<T>{v[3], v[1]};
+            }
+        }
+    }
+}
+
+// Pairwise pack-out (FFT kernels, C = CC in {1, 2}): bins k (even) and k+1 of a channel are one
+// complex slot, so a thread reads whole slots and emits whole 16-byte payload lines.
+template <typename T, int BITS, int SH, int CC>
+__device__ __forceinline__ void pack_out_pairs(unsigned char* smem, unsigned char* __restrict__ payload, double* absmax,
+                                               const Geom& g, long long f0, int nfl, int slots) {
+    constexpr int U = unit_values(BITS), UB = unit_bytes(BITS);
+    constexpr int V = U > 2 * CC ? U : 2 * CC;            // values per thread: whole units and whole slot pairs
+    constexpr int KB = V / CC;                            // bins per thread (even)
+    const bool le = g.le && (BITS % 8 == 0);
+    const int tasks = (g.N * CC) / V;
+    for (int fl = 0; fl < nfl; ++fl) {
+        unsigned char* dst = payload + (f0 + fl) * g.payload_stride;
+        u64 mx = 0;
+        for (int u = threadIdx.x; u < tasks; u += blockDim.x) {
+            u64 codes[V];
+            const int s0 = (u * KB) >> 1;                 // first complex slot
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                const cx<T>* buf = reinterpret_cast<const cx<T>*>(smem) + (long long)(fl * CC + c) * slots;
+#pragma unroll
+                for (int kk = 0; kk < KB / 2; ++kk) {
+                    const cx<T> z = buf[phys<T, SH>(s0 + kk)];
+                    const u64 a = abs_bits((double)z.x), b = abs_bits((double)z.y);
+                    mx = a > mx ? a : mx; mx = b > mx ? b : mx;
+                    codes[(2 * kk) * CC + c] = storage_code<T>(z.x, BITS);
+                    codes[(2 * kk + 1) * CC + c] = storage_code<T>(z.y, BITS);
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < V / U; ++w) {
+                u64 unit[U];
+#pragma unroll
+                for (int i = 0; i < U; ++i) unit[i] = codes[w * U + i];
+                uint32_t out[UB / 4];
+                pack_unit<BITS>(unit, le, out);
+                store_words<UB / 4>(dst + ((long long)u * (V / U) + w) * UB, out);
+            }
+        }
+        block_absmax_commit(mx, absmax, f0 + fl);
+    }
+}
+template <typename T, int SH, int CC>
+__device__ FRAD_NOINLINE void pack_out_pairs_any(int smem_off, unsigned char* __restrict__ payload, double* absmax,
+                                                   const Geom& g, long long f0, int nfl, int slots) {
+    FRAD_DYN_SMEM(smem_base_);
+    unsigned char* smem = smem_base_ + smem_off;
+    switch (g.bits) {
+        case 12: pack_out_pairs<T, 12, SH, CC>(smem, payload, absmax, g, f0, nfl, slots); break;
+        case 16: pack_out_pairs<T, 16, SH, CC>(smem, payload, absmax, g, f0, nfl, slots); break;
+        case 24: pack_out_pairs<T, 24, SH, CC>(smem, payload, absmax, g, f0, nfl, slots); break;
+        case 32: pack_out_pairs<T, 32, SH, CC>(smem, payload, absmax, g, f0, nfl, slots); break;
+        case 48: pack_out_pairs<T, 48, SH, CC>(smem, payload, absmax, g, f0, nfl, slots); break;
+        default: pack_out_pairs<T, 64, SH, CC>(smem, payload, absmax, g, f0, nfl, slots); break;
+    }
+}
+
+// Pairwise unpack-in (decode mirror of pack_out_pairs).
+template <int BITS, int SH, int CC>
+__device__ __forceinline__ void unpack_in_pairs(const unsigned char* __restrict__ payload, unsigned char* smem, const Geom& g,
+                                                long long f0, int nfl, int slots) {
+    constexpr int U = unit_values(BITS), UB = unit_bytes(BITS);
+    constexpr int V = U > 2 * CC ? U : 2 * CC, KB = V / CC;
+    const bool le = g.le && (BITS % 8 == 0);
+    const int tasks = (g.N * CC) / V;
+    for (int q = threadIdx.x; q < nfl * tasks; q += blockDim.x) {
+        const int fl = q / tasks, u = q - fl * tasks;
+        const unsigned char* src = payload + (f0 + fl) * g.payload_stride;
+        u64 codes[V];
+#pragma unroll
+        for (int w = 0; w < V / U; ++w) {
+            uint32_t in[UB / 4];
+            load_words<UB / 4>(src + ((long long)u * (V / U) + w) * UB, in);
+            u64 unit[U];
+            unpack_unit<BITS>(in, le, unit);
+#pragma unroll
+            for (int i = 0; i < U; ++i) codes[w * U + i] = unit[i];
+        }
+        const int s0 = (u * KB) >> 1;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            cx<double>* buf = reinterpret_cast<cx<double>*>(smem) + (long long)(fl * CC + c) * slots;
+#pragma unroll
+            for (int kk = 0; kk < KB / 2; ++kk)
+                buf[phys<double, SH>(s0 + kk)] = cx<double>{code_to_f64(codes[(2 * kk) * CC + c], BITS),
+                                                            code_to_f64(codes[(2 * kk + 1) * CC + c], BITS)};
+        }
+    }
+}
+template <int SH, int CC>
+__device__ FRAD_NOINLINE void unpack_in_pairs_any(const unsigned char* __restrict__ payload, int smem_off, const Geom& g,
+                                                    long long f0, int nfl, int slots) {
+    FRAD_DYN_SMEM(smem_base_);
+    unsigned char* smem = smem_base_ + smem_off;
+    switch (g.bits) {
+        case 12: unpack_in_pairs<12, SH, CC>(payload, smem, g, f0, nfl, slots); break;
+        case 16: unpack_in_pairs<16, SH, CC>(payload, smem, g, f0, nfl, slots); break;
+        case 24: unpack_in_pairs<24, SH, CC>(payload, smem, g, f0, nfl, slots); break;
+        case 32: unpack_in_pairs<32, SH, CC>(payload, smem, g, f0, nfl, slots); break;
+        case 48: unpack_in_pairs<48, SH, CC>(payload, smem, g, f0, nfl, slots); break;
+        default: unpack_in_pairs<64, SH, CC>(payload, smem, g, f0, nfl, slots); break;
+    }
+}
+
+// Quad store (decode epilogue, C = CC in {1, 2}): z[q] and z[M-1-q] of a channel are the four
+// consecutive samples 4q..4q+3 -> 4*CC contiguous float64 of the interleaved output.
+template <int SH, int CC>
+__device__ FRAD_NOINLINE void store_pcm_quads(int smem_off, double* __restrict__ out, const Geom& g,
+                                                long long f0, int nfl, int slots) {
+    FRAD_DYN_SMEM(smem_base_);
+    unsigned char* smem = smem_base_ + smem_off;
+    const int M = g.N >> 1, quads = g.N / 4;
+    for (int q = threadIdx.x; q < nfl * quads; q += blockDim.x) {
+        const int fl = q / quads, zq = q - fl * quads;
+        double row[4][CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const cx<double>* buf = reinterpret_cast<const cx<double>*>(smem) + (long long)(fl * CC + c) * slots;
+            const cx<double> a = buf[phys<double, SH>(zq)], b = buf[phys<double, SH>(M - 1 - zq)];
+            row[0][c] = a.x; row[2][c] = a.y; row[3][c] = b.x; row[1][c] = b.y;
+        }
+        double2* dst = reinterpret_cast<double2*>(out + (f0 + fl) * (long long)g.N * CC + (long long)zq * 4 * CC);
+        if constexpr (CC == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { double2 v; v.x = row[i][0]; v.y = row[i][1]; dst[i] = v; }
+        } else {
+            double2 v0, v1; v0.x = row[0][0]; v0.y = row[1][0]; v1.x = row[2][0]; v1.y = row[3][0];
+            dst[0] = v0; dst[1] = v1;
         }
     }
 }
 
 // Epilogue (encode): X[k] of every channel-frame in LDS -> absmax, storage cast, pack, store.
 // Payload order is bin-major / channel-minor (profile0.py:30: freqs.T.ravel()).
-template <typename T, int BITS, bool PADDED>
+template <typename T, int BITS, int SH>
 __device__ __forceinline__ void pack_out(unsigned char* smem, unsigned char* __restrict__ payload, double* absmax,
                                          const Geom& g, long long f0, int nfl, int slots, bool aligned) {
     constexpr int U = unit_values(BITS), UB = unit_bytes(BITS);
@@ -274,7 +508,7 @@ __device__ __forceinline__ void pack_out(unsigned char* smem, unsigned char* __r
             int k = (u * U) / C, c = (u * U) - k * C;
 #pragma unroll
             for (int i = 0; i < U; ++i) {
-                const T v = xslot<T, PADDED>(smem, fl * C + c, slots, k);
+                const T v = xslot<T, SH>(smem, fl * C + c, slots, k);
                 const u64 a = abs_bits((double)v);
                 mx = a > mx ? a : mx;
                 codes[i] = storage_code<T>(v, BITS);
@@ -285,7 +519,7 @@ __device__ __forceinline__ void pack_out(unsigned char* smem, unsigned char* __r
             store_words<UB / 4>(dst + (long long)u * UB, out);
         }
         if (units * U < NC) {                          // ragged tail or unaligned payload: byte-wise
-            auto value = [&](long long i) -> T { const int k = (int)(i / C); return xslot<T, PADDED>(smem, fl * C + (int)(i - (long long)k * C), slots, k); };
+            auto value = [&](long long i) -> T { const int k = (int)(i / C); return xslot<T, SH>(smem, fl * C + (int)(i - (long long)k * C), slots, k); };
             auto code_of = [&](long long i) -> u64 { return i < NC ? storage_code<T>(value(i), BITS) : 0; };
             for (long long s = (long long)units * UB + threadIdx.x; s < nbytes; s += blockDim.x)
                 dst[s] = (unsigned char)payload_byte(s, BITS, le, NC, code_of);
@@ -298,21 +532,23 @@ __device__ __forceinline__ void pack_out(unsigned char* smem, unsigned char* __r
     }
 }
 
-template <typename T, bool PADDED>
-__device__ __forceinline__ void pack_out_any(unsigned char* smem, unsigned char* __restrict__ payload, double* absmax,
+template <typename T, int SH>
+__device__ FRAD_NOINLINE void pack_out_any(int smem_off, unsigned char* __restrict__ payload, double* absmax,
                                              const Geom& g, long long f0, int nfl, int slots, bool aligned) {
+    FRAD_DYN_SMEM(smem_base_);
+    unsigned char* smem = smem_base_ + smem_off;
     switch (g.bits) {
-        case 12: pack_out<T, 12, PADDED>(smem, payload, absmax, g, f0, nfl, slots, aligned); break;
-        case 16: pack_out<T, 16, PADDED>(smem, payload, absmax, g, f0, nfl, slots, aligned); break;
-        case 24: pack_out<T, 24, PADDED>(smem, payload, absmax, g, f0, nfl, slots, aligned); break;
-        case 32: pack_out<T, 32, PADDED>(smem, payload, absmax, g, f0, nfl, slots, aligned); break;
-        case 48: pack_out<T, 48, PADDED>(smem, payload, absmax, g, f0, nfl, slots, aligned); break;
-        default: pack_out<T, 64, PADDED>(smem, payload, absmax, g, f0, nfl, slots, aligned); break;
+        case 12: pack_out<T, 12, SH>(smem, payload, absmax, g, f0, nfl, slots, aligned); break;
+        case 16: pack_out<T, 16, SH>(smem, payload, absmax, g, f0, nfl, slots, aligned); break;
+        case 24: pack_out<T, 24, SH>(smem, payload, absmax, g, f0, nfl, slots, aligned); break;
+        case 32: pack_out<T, 32, SH>(smem, payload, absmax, g, f0, nfl, slots, aligned); break;
+        case 48: pack_out<T, 48, SH>(smem, payload, absmax, g, f0, nfl, slots, aligned); break;
+        default: pack_out<T, 64, SH>(smem, payload, absmax, g, f0, nfl, slots, aligned); break;
     }
 }
 
 // Stage-in (decode): payload -> unpack -> scrub -> X[k] (float64) in LDS.
-template <int BITS, bool PADDED>
+template <int BITS, int SH>
 __device__ __forceinline__ void unpack_in(const unsigned char* __restrict__ payload, unsigned char* smem, const Geom& g,
                                           long long f0, int nfl, int slots, bool aligned) {
     constexpr int U = unit_values(BITS), UB = unit_bytes(BITS);
@@ -329,33 +565,37 @@ __device__ __forceinline__ void unpack_in(const unsigned char* __restrict__ payl
             int k = (u * U) / C, c = (u * U) - k * C;
 #pragma unroll
             for (int i = 0; i < U; ++i) {
-                xslot<double, PADDED>(smem, fl * C + c, slots, k) = code_to_f64(codes[i], BITS);
+                xslot<double, SH>(smem, fl * C + c, slots, k) = code_to_f64(codes[i], BITS);
                 if (++c == C) { c = 0; ++k; }
             }
         }
         for (int i = units * U + threadIdx.x; i < NC; i += blockDim.x) {
             const int k = i / C, c = i - k * C;
-            xslot<double, PADDED>(smem, fl * C + c, slots, k) = code_to_f64(code_from_bytes(src, i, BITS, le), BITS);
+            xslot<double, SH>(smem, fl * C + c, slots, k) = code_to_f64(code_from_bytes(src, i, BITS, le), BITS);
         }
     }
 }
-template <bool PADDED>
-__device__ __forceinline__ void unpack_in_any(const unsigned char* __restrict__ payload, unsigned char* smem, const Geom& g,
+template <int SH>
+__device__ FRAD_NOINLINE void unpack_in_any(const unsigned char* __restrict__ payload, int smem_off, const Geom& g,
                                               long long f0, int nfl, int slots, bool aligned) {
+    FRAD_DYN_SMEM(smem_base_);
+    unsigned char* smem = smem_base_ + smem_off;
     switch (g.bits) {
-        case 12: unpack_in<12, PADDED>(payload, smem, g, f0, nfl, slots, aligned); break;
-        case 16: unpack_in<16, PADDED>(payload, smem, g, f0, nfl, slots, aligned); break;
-        case 24: unpack_in<24, PADDED>(payload, smem, g, f0, nfl, slots, aligned); break;
-        case 32: unpack_in<32, PADDED>(payload, smem, g, f0, nfl, slots, aligned); break;
-        case 48: unpack_in<48, PADDED>(payload, smem, g, f0, nfl, slots, aligned); break;
-        default: unpack_in<64, PADDED>(payload, smem, g, f0, nfl, slots, aligned); break;
+        case 12: unpack_in<12, SH>(payload, smem, g, f0, nfl, slots, aligned); break;
+        case 16: unpack_in<16, SH>(payload, smem, g, f0, nfl, slots, aligned); break;
+        case 24: unpack_in<24, SH>(payload, smem, g, f0, nfl, slots, aligned); break;
+        case 32: unpack_in<32, SH>(payload, smem, g, f0, nfl, slots, aligned); break;
+        case 48: unpack_in<48, SH>(payload, smem, g, f0, nfl, slots, aligned); break;
+        default: unpack_in<64, SH>(payload, smem, g, f0, nfl, slots, aligned); break;
     }
 }
 
 // Epilogue (decode): time samples in LDS -> interleaved float64 [N, C] rows, 16 bytes per lane.
-template <bool PADDED, bool PERMUTE>
-__device__ __forceinline__ void store_pcm_f64(unsigned char* smem, double* __restrict__ out, const Geom& g,
+template <int SH, bool PERMUTE>
+__device__ FRAD_NOINLINE void store_pcm_f64(int smem_off, double* __restrict__ out, const Geom& g,
                                               long long f0, int nfl, int slots) {
+    FRAD_DYN_SMEM(smem_base_);
+    unsigned char* smem = smem_base_ + smem_off;
     const int N = g.N, C = g.C, NC = N * C;
     const int pairs = NC / 2;                       // out + f*NC is 16-byte aligned when NC is even
     for (int fl = 0; fl < nfl; ++fl) {
@@ -365,17 +605,99 @@ __device__ __forceinline__ void store_pcm_f64(unsigned char* smem, double* __res
                 const int e = 2 * p;
                 int n = e / C, c = e - n * C;
                 double2 v;
-                v.x = xslot<double, PADDED>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n);
+                v.x = xslot<double, SH>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n);
                 if (++c == C) { c = 0; ++n; }
-                v.y = xslot<double, PADDED>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n);
+                v.y = xslot<double, SH>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n);
                 reinterpret_cast<double2*>(dst)[p] = v;
             }
         } else {
             for (int e = threadIdx.x; e < NC; e += blockDim.x) {
                 const int n = e / C, c = e - n * C;
-                dst[e] = xslot<double, PADDED>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n);
+                dst[e] = xslot<double, SH>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Channel-group mode: a frame whose channels do not fit the 160 KiB LDS together (e.g. 7.1 at
+// N = 4096 in float64) is transformed `cg` channels at a time by one block.  The interleaved
+// payload / PCM rows are then touched per value instead of per 16-byte unit.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int LG, int SH>
+__device__ FRAD_NOINLINE void stage_in_pcm_group(const unsigned char* __restrict__ pcm, int smem_off, const Geom& g,
+                                                   long long f, int slots, int c0, int cgn) {
+    FRAD_DYN_SMEM(smem_base_);
+    unsigned char* smem = smem_base_ + smem_off;
+    const int N = g.N, C = g.C;
+    const unsigned char* src = pcm + ((f * g.frame_stride * C) << LG);
+    for (int q = threadIdx.x; q < N * cgn; q += blockDim.x) {
+        const int n = q / cgn, j = q - n * cgn;
+        const long long e = (long long)n * C + c0 + j;
+        const T v = n < g.n_valid ? cvt_pcm<T>(load_raw(src + (e << LG), LG), g.dtype, g.raw_be) : (T)0;
+        xslot<T, SH>(smem, j, slots, makhoul(n, N)) = v;
+    }
+}
+
+template <typename T, int SH>
+__device__ FRAD_NOINLINE void pack_out_group(int smem_off, unsigned char* __restrict__ payload, double* absmax,
+                                               const Geom& g, long long f, int slots, int c0, int cgn) {
+    FRAD_DYN_SMEM(smem_base_);
+    unsigned char* smem = smem_base_ + smem_off;
+    const int N = g.N, C = g.C, bits = g.bits;
+    const bool le = g.le && (bits % 8 == 0);
+    unsigned char* dst = payload + f * g.payload_stride;
+    u64 mx = 0;
+    if (bits == 12) {                                   // host guarantees C, c0 and cgn even: pairs stay in the group
+        const int half = cgn / 2;
+        for (int q = threadIdx.x; q < N * half; q += blockDim.x) {
+            const int k = q / half, p = q - k * half;
+            const T a = xslot<T, SH>(smem, 2 * p, slots, k), b = xslot<T, SH>(smem, 2 * p + 1, slots, k);
+            const u64 ma = abs_bits((double)a), mb = abs_bits((double)b);
+            mx = ma > mx ? ma : mx; mx = mb > mx ? mb : mx;
+            const uint32_t ca = (uint32_t)storage_code<T>(a, 12), cb = (uint32_t)storage_code<T>(b, 12);
+            const long long o = ((long long)k * C + c0 + 2 * p) / 2 * 3;
+            dst[o] = (unsigned char)(ca >> 4); dst[o + 1] = (unsigned char)(((ca & 15) << 4) | (cb >> 8)); dst[o + 2] = (unsigned char)cb;
+        }
+    } else {
+        const int nb = bits >> 3;
+        for (int q = threadIdx.x; q < N * cgn; q += blockDim.x) {
+            const int k = q / cgn, j = q - k * cgn;
+            const T v = xslot<T, SH>(smem, j, slots, k);
+            const u64 a = abs_bits((double)v);
+            mx = a > mx ? a : mx;
+            const u64 code = storage_code<T>(v, bits);
+            const long long o = ((long long)k * C + c0 + j) * nb;
+            for (int b = 0; b < nb; ++b) dst[o + b] = (unsigned char)code_byte(code, bits, le, b);
+        }
+    }
+    block_absmax_commit(mx, absmax, f);
+}
+
+template <int SH>
+__device__ FRAD_NOINLINE void unpack_in_group(const unsigned char* __restrict__ payload, int smem_off, const Geom& g,
+                                                long long f, int slots, int c0, int cgn) {
+    FRAD_DYN_SMEM(smem_base_);
+    unsigned char* smem = smem_base_ + smem_off;
+    const int N = g.N, C = g.C;
+    const bool le = g.le && (g.bits % 8 == 0);
+    const unsigned char* src = payload + f * g.payload_stride;
+    for (int q = threadIdx.x; q < N * cgn; q += blockDim.x) {
+        const int k = q / cgn, j = q - k * cgn;
+        xslot<double, SH>(smem, j, slots, k) = code_to_f64(code_from_bytes(src, (long long)k * C + c0 + j, g.bits, le), g.bits);
+    }
+}
+
+template <int SH>
+__device__ FRAD_NOINLINE void store_pcm_group(int smem_off, double* __restrict__ out, const Geom& g,
+                                                long long f, int slots, int c0, int cgn) {
+    FRAD_DYN_SMEM(smem_base_);
+    unsigned char* smem = smem_base_ + smem_off;
+    const int N = g.N, C = g.C;
+    double* dst = out + f * (long long)N * C;
+    for (int q = threadIdx.x; q < N * cgn; q += blockDim.x) {
+        const int n = q / cgn, j = q - n * cgn;
+        dst[(long long)n * C + c0 + j] = xslot<double, SH>(smem, j, slots, makhoul(n, N));
     }
 }
 
@@ -384,47 +706,97 @@ __device__ __forceinline__ void store_pcm_f64(unsigned char* smem, double* __res
 // block = fpb frames x C channels x TEAM lanes (rounded up to whole waves).
 // =============================================================================================
 template <typename T, int LOG2M, int LG, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_p0_fwd(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload,
+__global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? 2 : 1)) k_p0_fwd(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload,
                                                   double* absmax, const cx<T>* __restrict__ tw, const cx<T>* __restrict__ post,
                                                   Geom g, int aligned_in, int aligned_out) {
-    constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM, SLOTS = padded_slots(M);
+    constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM, SLOTS = padded_slots(M), SH = Plan<LOG2M>::SH;
     FRAD_DYN_SMEM(smem);
     const long long f0 = (long long)blockIdx.x * g.fpb;
     const long long rem = g.n_frames - f0;
     const int nfl = rem < g.fpb ? (int)rem : g.fpb;
-    stage_in_pcm<T, LG, true, true>(pcm, smem, g, f0, nfl, SLOTS, aligned_in != 0);
-    __syncthreads();
     // blockDim.x == fpb * C * TEAM exactly (a whole number of waves): every team owns a buffer.
-    // In a short last block the teams of the missing frames transform whatever the LDS holds and
-    // nobody reads their result; that keeps every barrier of the multi-wave teams uniform.
+    // In a short last block the spare teams transform whatever the LDS holds and nobody reads
+    // their result; that keeps the multi-wave teams' barriers uniform.
     const int cf = threadIdx.x / TEAM, t = threadIdx.x - cf * TEAM;
     cx<T>* buf = reinterpret_cast<cx<T>*>(smem) + (long long)cf * SLOTS;
+    if (g.in_mode) stage_in_quads<T, LG, SH>(pcm, 0, g, f0, nfl, SLOTS);
+    else stage_in_pcm<T, LG, SH, true>(pcm, 0, g, f0, nfl, SLOTS, aligned_in != 0);
+    __syncthreads();
     fft_team<T, LOG2M, false>(buf, t, tw);
     dct_post<T, LOG2M>(buf, t, post);
     __syncthreads();
-    pack_out_any<T, true>(smem, payload, absmax, g, f0, nfl, SLOTS, aligned_out != 0);
+    if (g.cc_fast == 2) pack_out_pairs_any<T, SH, 2>(0, payload, absmax, g, f0, nfl, SLOTS);
+    else if (g.cc_fast == 1) pack_out_pairs_any<T, SH, 1>(0, payload, absmax, g, f0, nfl, SLOTS);
+    else pack_out_any<T, SH>(0, payload, absmax, g, f0, nfl, SLOTS, aligned_out != 0);
+}
+
+// Channel-group variant: one frame per block, `g.cg` channels per pass (see above).  A kernel of
+// its own so that the common kernel's register allocation is not disturbed by the second copy of
+// the transform.
+template <typename T, int LOG2M, int LG>
+__global__ void __launch_bounds__(1024) k_p0_fwd_grp(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload,
+                                                      double* absmax, const cx<T>* __restrict__ tw, const cx<T>* __restrict__ post, Geom g) {
+    constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM, SLOTS = padded_slots(M), SH = Plan<LOG2M>::SH;
+    FRAD_DYN_SMEM(smem);
+    const long long f0 = blockIdx.x;
+    const int cf = threadIdx.x / TEAM, t = threadIdx.x - cf * TEAM;
+    cx<T>* buf = reinterpret_cast<cx<T>*>(smem) + (long long)cf * SLOTS;
+    for (int c0 = 0; c0 < g.C; c0 += g.cg) {
+        const int cgn = g.C - c0 < g.cg ? g.C - c0 : g.cg;
+        stage_in_pcm_group<T, LG, SH>(pcm, 0, g, f0, SLOTS, c0, cgn);
+        __syncthreads();
+        fft_team<T, LOG2M, false>(buf, t, tw);
+        dct_post<T, LOG2M>(buf, t, post);
+        __syncthreads();
+        pack_out_group<T, SH>(0, payload, absmax, g, f0, SLOTS, c0, cgn);
+        __syncthreads();
+    }
 }
 
 // =============================================================================================
 // K4  profile 0 decode (always float64, as the reference widens before idct).
 // =============================================================================================
 template <int LOG2M, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_p0_inv(const unsigned char* __restrict__ payload, double* __restrict__ out,
+__global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? 2 : 1)) k_p0_inv(const unsigned char* __restrict__ payload, double* __restrict__ out,
                                                   const cx<double>* __restrict__ tw, const cx<double>* __restrict__ post,
                                                   Geom g, int aligned_in) {
-    constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM, SLOTS = padded_slots(M);
+    constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM, SLOTS = padded_slots(M), SH = Plan<LOG2M>::SH;
     FRAD_DYN_SMEM(smem);
     const long long f0 = (long long)blockIdx.x * g.fpb;
     const long long rem = g.n_frames - f0;
     const int nfl = rem < g.fpb ? (int)rem : g.fpb;
-    unpack_in_any<true>(payload, smem, g, f0, nfl, SLOTS, aligned_in != 0);
-    __syncthreads();
     const int cf = threadIdx.x / TEAM, t = threadIdx.x - cf * TEAM;
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem) + (long long)cf * SLOTS;
+    if (g.cc_fast == 2) unpack_in_pairs_any<SH, 2>(payload, 0, g, f0, nfl, SLOTS);
+    else if (g.cc_fast == 1) unpack_in_pairs_any<SH, 1>(payload, 0, g, f0, nfl, SLOTS);
+    else unpack_in_any<SH>(payload, 0, g, f0, nfl, SLOTS, aligned_in != 0);
+    __syncthreads();
     dct_pre_inverse<double, LOG2M>(buf, t, post);
     fft_team<double, LOG2M, true>(buf, t, tw);
     __syncthreads();
-    store_pcm_f64<true, true>(smem, out, g, f0, nfl, SLOTS);
+    if (g.in_mode == 2) store_pcm_quads<SH, 2>(0, out, g, f0, nfl, SLOTS);
+    else if (g.in_mode == 1) store_pcm_quads<SH, 1>(0, out, g, f0, nfl, SLOTS);
+    else store_pcm_f64<SH, true>(0, out, g, f0, nfl, SLOTS);
+}
+
+template <int LOG2M>
+__global__ void __launch_bounds__(1024) k_p0_inv_grp(const unsigned char* __restrict__ payload, double* __restrict__ out,
+                                                      const cx<double>* __restrict__ tw, const cx<double>* __restrict__ post, Geom g) {
+    constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM, SLOTS = padded_slots(M), SH = Plan<LOG2M>::SH;
+    FRAD_DYN_SMEM(smem);
+    const long long f0 = blockIdx.x;
+    const int cf = threadIdx.x / TEAM, t = threadIdx.x - cf * TEAM;
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem) + (long long)cf * SLOTS;
+    for (int c0 = 0; c0 < g.C; c0 += g.cg) {
+        const int cgn = g.C - c0 < g.cg ? g.C - c0 : g.cg;
+        unpack_in_group<SH>(payload, 0, g, f0, SLOTS, c0, cgn);
+        __syncthreads();
+        dct_pre_inverse<double, LOG2M>(buf, t, post);
+        fft_team<double, LOG2M, true>(buf, t, tw);
+        __syncthreads();
+        store_pcm_group<SH>(0, out, g, f0, SLOTS, c0, cgn);
+        __syncthreads();
+    }
 }
 
 // =============================================================================================
@@ -440,7 +812,7 @@ __global__ void __launch_bounds__(256) k_p0_fwd_direct(const unsigned char* __re
     const long long f0 = blockIdx.x;
     T* x = reinterpret_cast<T*>(smem);
     T* X = x + (long long)N * C;
-    stage_in_pcm<T, LG, false, false>(pcm, smem, g, f0, 1, N, aligned_in != 0);
+    stage_in_pcm<T, LG, -1, false>(pcm, 0, g, f0, 1, N, aligned_in != 0);
     __syncthreads();
     const double inv_n = 1.0 / (double)N;
     const unsigned fourN = 4u * (unsigned)N;
@@ -457,7 +829,7 @@ __global__ void __launch_bounds__(256) k_p0_fwd_direct(const unsigned char* __re
         X[(long long)c * N + k] = (T)(acc * inv_n);
     }
     __syncthreads();
-    pack_out_any<T, false>(reinterpret_cast<unsigned char*>(X), payload, absmax, g, f0, 1, N, aligned_out != 0);
+    pack_out_any<T, -1>((int)((long long)N * C * sizeof(T)), payload, absmax, g, f0, 1, N, aligned_out != 0);
 }
 
 template <int UNUSED>
@@ -468,7 +840,7 @@ __global__ void __launch_bounds__(256) k_p0_inv_direct(const unsigned char* __re
     const long long f0 = blockIdx.x;
     double* X = reinterpret_cast<double*>(smem);
     double* x = X + (long long)N * C;
-    unpack_in_any<false>(payload, smem, g, f0, 1, N, aligned_in != 0);
+    unpack_in_any<-1>(payload, 0, g, f0, 1, N, aligned_in != 0);
     __syncthreads();
     const unsigned fourN = 4u * (unsigned)N;
     for (int q = threadIdx.x; q < N * C; q += blockDim.x) {
@@ -484,7 +856,7 @@ __global__ void __launch_bounds__(256) k_p0_inv_direct(const unsigned char* __re
         x[(long long)c * N + n] = Xc[0] + 2.0 * acc;
     }
     __syncthreads();
-    store_pcm_f64<false, false>(reinterpret_cast<unsigned char*>(x), out, g, f0, 1, N);
+    store_pcm_f64<-1, false>((int)((long long)N * C * sizeof(double)), out, g, f0, 1, N);
 }
 
 }  // namespace frad

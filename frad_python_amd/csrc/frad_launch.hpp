@@ -11,7 +11,7 @@ struct Tables { void* tw = nullptr; void* post = nullptr; };
 // launch geometry of the LDS-resident FFT kernels
 struct FastCfg {
     bool ok = false;
-    int log2m = 0, team = 0, fpb = 0, threads = 0;
+    int log2m = 0, team = 0, fpb = 0, threads = 0, cg = 0;
     size_t lds = 0;
 };
 

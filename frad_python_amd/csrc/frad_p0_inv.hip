@@ -9,6 +9,11 @@ int launch_p0_inv(const FastCfg& c, dim3 grid, hipStream_t s, const unsigned cha
     const cx<double>* post = static_cast<const cx<double>*>(tb.post);
 #define FRAD_GO(L, MAXT) do { allow_lds(k_p0_inv<L, MAXT>, c.lds); \
         hipLaunchKernelGGL((k_p0_inv<L, MAXT>), grid, dim3(c.threads), c.lds, s, pay, out, tw, post, g, ai); } while (0)
+#define FRAD_GRP(L) case L: allow_lds(k_p0_inv_grp<L>, c.lds); hipLaunchKernelGGL((k_p0_inv_grp<L>), grid, dim3(c.threads), c.lds, s, pay, out, tw, post, g); return 0;
+    if (c.cg < g.C) {
+        switch (c.log2m) { FRAD_GRP(8) FRAD_GRP(9) FRAD_GRP(10) FRAD_GRP(11) FRAD_GRP(12) FRAD_GRP(13) default: return -2; }
+    }
+#undef FRAD_GRP
 #define FRAD_CASE(L) case L: if (c.threads <= 256) FRAD_GO(L, 256); else if (c.threads <= 512) FRAD_GO(L, 512); else FRAD_GO(L, 1024); return 0;
     switch (c.log2m) {
         FRAD_CASE(6) FRAD_CASE(7) FRAD_CASE(8) FRAD_CASE(9) FRAD_CASE(10) FRAD_CASE(11) FRAD_CASE(12) FRAD_CASE(13)
@@ -16,6 +21,22 @@ int launch_p0_inv(const FastCfg& c, dim3 grid, hipStream_t s, const unsigned cha
     }
 #undef FRAD_CASE
 #undef FRAD_GO
+}
+
+// diagnostics: what the runtime says about residency of the N = 2048 kernels at a given LDS size
+extern "C" int frad_debug_occupancy(int threads, int lds_bytes, int* blocks_inv, int* lds_per_cu, int* lds_per_block_optin, int* cus) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, 0) != hipSuccess) return -3;
+    *lds_per_cu = (int)p.maxSharedMemoryPerMultiProcessor; *lds_per_block_optin = (int)p.sharedMemPerBlockOptin; *cus = p.multiProcessorCount;
+    allow_lds(k_p0_inv<10, 256>, (size_t)lds_bytes);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_inv, k_p0_inv<10, 256>, threads, (size_t)lds_bytes) != hipSuccess) return -3;
+    int small = 0;
+    allow_lds(k_p4_unpack_slow<0>, (size_t)lds_bytes);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&small, k_p4_unpack_slow<0>, threads, (size_t)lds_bytes) != hipSuccess) return -3;
+    *cus = small;                       // reused: blocks/CU of a tiny-register kernel at the same LDS request
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_p0_inv<10, 256>)) == hipSuccess) *lds_per_block_optin = fa.numRegs;
+    return 0;
 }
 
 }  // namespace frad

@@ -65,6 +65,7 @@ template <typename F> void launch(dim3 grid, dim3 block, size_t lds, F&& body) {
 
 inline void __syncthreads() { emu::blk->bar.arrive_and_wait(); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 inline void __builtin_amdgcn_wave_barrier() { emu::blk->bar.arrive_and_wait(); }
 
 inline unsigned long long __shfl_xor(unsigned long long v, int mask, int /*width*/) {
@@ -128,6 +129,11 @@ inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
+struct hipDeviceProp_t { size_t maxSharedMemoryPerMultiProcessor = 163840, sharedMemPerBlockOptin = 163840; int multiProcessorCount = 1; };
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = hipDeviceProp_t(); return hipSuccess; }
+struct hipFuncAttributes { int numRegs = 0; };
+inline hipError_t hipFuncGetAttributes(hipFuncAttributes*, const void*) { return hipSuccess; }
+template <typename K> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 1; return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 template <typename K, typename... A>
 inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t, A... args) {
