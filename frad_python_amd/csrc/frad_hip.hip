@@ -323,9 +323,11 @@ int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
         }
         if (c.cg == C && ao && C <= 2 && ((long long)N * C) % 32 == 0) g.cc_fast = C;
         dim3 grid((unsigned)((n_frames + c.fpb - 1) / c.fpb));
-        rc = f32 ? launch_p0_fwd_f32(lg, c, grid, s, in, out, absmax, tb, g, ai, ao)
-                 : launch_p0_fwd_f64(lg, c, grid, s, in, out, absmax, tb, g, ai, ao);
-        if (rc != FRAD_OK) return rc;
+        if (!launch_p0_fwd_pers(f32, lg, c, s, in, out, absmax, tb, g, ao)) {
+            rc = f32 ? launch_p0_fwd_f32(lg, c, grid, s, in, out, absmax, tb, g, ai, ao)
+                     : launch_p0_fwd_f64(lg, c, grid, s, in, out, absmax, tb, g, ai, ao);
+            if (rc != FRAD_OK) return rc;
+        }
     } else {
         const size_t lds = 2 * (size_t)N * C * (f32 ? 4 : 8);
         if (lds > (size_t)kLdsBytes || n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
@@ -362,8 +364,10 @@ int frad_p0_digital(const void* payload, int64_t payload_stride, int64_t n_frame
         if (c.cg == C && ai && C <= 2 && ((long long)N * C) % 32 == 0) g.cc_fast = C;
         if (c.cg == C && C <= 2 && aligned16(pcm_out)) g.in_mode = C;      // decode: quad store for C = 1 / 2
         dim3 grid((unsigned)((n_frames + c.fpb - 1) / c.fpb));
-        rc = launch_p0_inv(c, grid, s, in, pcm_out, tb, g, ai);
-        if (rc != FRAD_OK) return rc;
+        if (!launch_p0_inv_pers(c, s, in, pcm_out, tb, g)) {
+            rc = launch_p0_inv(c, grid, s, in, pcm_out, tb, g, ai);
+            if (rc != FRAD_OK) return rc;
+        }
     } else {
         const size_t lds = 2 * (size_t)N * C * 8;
         if (lds > (size_t)kLdsBytes || n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;

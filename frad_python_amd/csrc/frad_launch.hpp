@@ -30,4 +30,9 @@ int launch_p0_fwd_f32(int lg, const FastCfg& c, dim3 grid, hipStream_t s, const 
 int launch_p0_inv(const FastCfg& c, dim3 grid, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb,
                   const Geom& g, int aligned_in);
 
+// persistent kernels (frad_p0_pers.hip): return 1 when they took the launch, 0 when not applicable
+int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const unsigned char* pcm, unsigned char* pay,
+                       double* absmax, const Tables& tb, Geom g, int aligned_out);
+int launch_p0_inv_pers(const FastCfg& c, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb, Geom g);
+
 }  // namespace frad

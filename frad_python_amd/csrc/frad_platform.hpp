@@ -13,5 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #define FRAD_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+// make a lane value opaque to the optimiser (used to stop loop-invariant code motion from parking
+// hundreds of per-lane LDS addresses in VGPRs across a persistent loop)
+#define FRAD_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 #include <stdint.h>

@@ -62,6 +62,7 @@ template <typename F> void launch(dim3 grid, dim3 block, size_t lds, F&& body) {
 #define blockDim emu::b_dim
 #define gridDim emu::g_dim
 #define FRAD_DYN_SMEM(name) unsigned char* name = emu::smem_base()
+#define FRAD_OPAQUE(x) asm volatile("" : "+r"(x))
 
 inline void __syncthreads() { emu::blk->bar.arrive_and_wait(); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
@@ -124,6 +125,8 @@ constexpr hipError_t hipSuccess = 0;
 typedef void* hipStream_t;
 enum { hipMemcpyHostToDevice = 1, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+enum { hipDeviceAttributeMultiprocessorCount = 1 };
+inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 3; return hipSuccess; }
 template <typename P> inline hipError_t hipMalloc(P** p, size_t n) { *p = static_cast<P*>(std::aligned_alloc(64, (n + 63) / 64 * 64)); return *p ? 0 : 2; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std::memcpy(d, s, n); return hipSuccess; }
