@@ -169,6 +169,46 @@ __device__ __forceinline__ void fft_pass(cx<T>* buf, int t, const cx<T>* __restr
     team_sync<TEAM>();
 }
 
+// The same pass with its twiddles in a lane-linear table (the persistent kernels keep it in LDS):
+// entry ((nb_eff * (R-1) + j-1) * KW + kk) = W_{NS*R}^(j * k), with KW = min(NS, TEAM), kk = t mod KW,
+// nb_eff = nb when NS > TEAM else 0 -- consecutive lanes read consecutive (or identical, broadcast)
+// slots, so the reads are free of bank conflicts, and they are issued next to their use.
+template <int TEAM, int R, int NS, int M> __host__ __device__ constexpr int pass_table_size() {
+    return NS == 1 ? 0 : (NS > TEAM ? (M / R / TEAM) : 1) * (R - 1) * (NS > TEAM ? TEAM : NS);
+}
+template <typename T, int M, int TEAM, int R, int NS, bool INV, int SH>
+__device__ __forceinline__ void fft_pass_lt(cx<T>* buf, int t, const cx<T>* ptab) {
+    constexpr int NB = M / R / TEAM, KW = NS > TEAM ? TEAM : NS;
+    static_assert(NB >= 1 && NB * R * TEAM == M, "pass geometry");
+    cx<T> v[NB][R];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int b = t + nb * TEAM;
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[nb][j] = buf[phys<T, SH>(b + j * (M / R))];
+    }
+    team_sync<TEAM>();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int b = t + nb * TEAM;
+        const int k = b & (NS - 1);
+        if constexpr (NS > 1) {
+            const int kk = t & (KW - 1), nbe = NS > TEAM ? nb : 0;
+#pragma unroll
+            for (int j = 1; j < R; ++j) {
+                cx<T> ww = ptab[(nbe * (R - 1) + (j - 1)) * KW + kk];
+                if constexpr (INV) ww.y = -ww.y;
+                v[nb][j] = cmul(v[nb][j], ww);
+            }
+        }
+        dft<R, INV>(v[nb]);
+        const int base = (b - k) * R + k;
+#pragma unroll
+        for (int j = 0; j < R; ++j) buf[phys<T, SH>(base + j * NS)] = v[nb][j];
+    }
+    team_sync<TEAM>();
+}
+
 // Pass schedules.  P = points per lane = max radix, TEAM = M / P lanes per channel-frame.
 template <int LOG2M> struct Plan;
 template <> struct Plan<6>  { static constexpr int TEAM = 16,  SH = 2; };   // M = 64   : 4 4 4
@@ -224,8 +264,9 @@ __device__ __forceinline__ int makhoul(int n, int N) { return (n & 1) ? N - 1 - 
 // post[k] = { w_k, g_k } with w_k = exp(-i pi k / 2N), g_k = -i w_k exp(-2 pi i k / N), k in [0, M/2]
 //
 // forward: Z (FFT of the packed sequence) -> X[k] = (1/N) sum x[n] cos(pi k (2n+1) / 2N), in place.
-template <typename T, int LOG2M>
+template <typename T, int LOG2M, int PS = 2>
 __device__ __forceinline__ void dct_post(cx<T>* buf, int t, const cx<T>* __restrict__ post) {
+    constexpr int GOFF = PS == 2 ? 1 : (1 << LOG2M) / 2 + 1;   // where g_k lives relative to w_k
     constexpr int M = 1 << LOG2M, N = 2 * M, TEAM = Plan<LOG2M>::TEAM, SH = Plan<LOG2M>::SH;
     constexpr int PP = (M / 2) / TEAM;         // pairs per lane (pair M/2 goes to lane 0 on top)
     constexpr T sc = (T)1 / (T)(2 * N);
@@ -237,7 +278,7 @@ __device__ __forceinline__ void dct_post(cx<T>* buf, int t, const cx<T>* __restr
         const int k = (i < PP) ? t + i * TEAM : M / 2;
         if (i == PP && t != 0) continue;
         const cx<T> zk = buf[phys<T, SH>(k)], zp = conj(buf[phys<T, SH>((M - k) & (M - 1))]);
-        const cx<T> p = cmul(zk + zp, post[2 * k]), q = cmul(zk - zp, post[2 * k + 1]);
+        const cx<T> p = cmul(zk + zp, post[PS * k]), q = cmul(zk - zp, post[PS * k + GOFF]);
         S[i] = p + q; D[i] = p - q;
     }
     team_sync<TEAM>();
@@ -257,8 +298,9 @@ __device__ __forceinline__ void dct_post(cx<T>* buf, int t, const cx<T>* __restr
 
 // inverse: X (N reals, 'forward'-normalised DCT-II coefficients) -> Z' = Z / M, in place, so that
 // the unscaled inverse FFT returns the packed time sequence.
-template <typename T, int LOG2M>
+template <typename T, int LOG2M, int PS = 2>
 __device__ __forceinline__ void dct_pre_inverse(cx<T>* buf, int t, const cx<T>* __restrict__ post) {
+    constexpr int GOFF = PS == 2 ? 1 : (1 << LOG2M) / 2 + 1;
     constexpr int M = 1 << LOG2M, N = 2 * M, TEAM = Plan<LOG2M>::TEAM, SH = Plan<LOG2M>::SH;
     constexpr int PP = (M / 2) / TEAM;
     cx<T> A[PP + 1], B[PP + 1];
@@ -272,8 +314,8 @@ __device__ __forceinline__ void dct_pre_inverse(cx<T>* buf, int t, const cx<T>* 
         const T a = real_slot<T, SH>(buf, M - k), b = real_slot<T, SH>(buf, k > 0 ? M + k : M);
         const cx<T> u = {xk, -xnk};
         const cx<T> s = {(a + b) * K<T>::s2, (b - a) * K<T>::s2};
-        A[i] = cmul(u + s, conj(post[2 * k]));
-        B[i] = cmul(u - s, conj(post[2 * k + 1]));
+        A[i] = cmul(u + s, conj(post[PS * k]));
+        B[i] = cmul(u - s, conj(post[PS * k + GOFF]));
     }
     team_sync<TEAM>();
 #pragma unroll

@@ -3,10 +3,11 @@
 // split over several objects only so that hipcc can build them in parallel.
 #pragma once
 #include "frad_kernels.hpp"
+#include <vector>
 
 namespace frad {
 
-struct Tables { void* tw = nullptr; void* post = nullptr; };
+struct Tables { void* tw = nullptr; void* post = nullptr; void* blob = nullptr; };   // blob: LDS image of the persistent kernels
 
 // launch geometry of the LDS-resident FFT kernels
 struct FastCfg {
@@ -30,6 +31,8 @@ int launch_p0_fwd_f32(int lg, const FastCfg& c, dim3 grid, hipStream_t s, const 
 int launch_p0_inv(const FastCfg& c, dim3 grid, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb,
                   const Geom& g, int aligned_in);
 
+size_t pers_blob_build(int log2m, bool f32, std::vector<unsigned char>& bytes,
+                       void (*unit)(long long, long long, long double&, long double&));
 // persistent kernels (frad_p0_pers.hip): return 1 when they took the launch, 0 when not applicable
 int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const unsigned char* pcm, unsigned char* pay,
                        double* absmax, const Tables& tb, Geom g, int aligned_out);

@@ -2,6 +2,7 @@
 #include "frad_persistent.hpp"
 #include "frad_launch.hpp"
 #include <cstdlib>
+#include <vector>
 
 namespace frad {
 namespace {
@@ -24,29 +25,62 @@ void go_fwd(int threads, size_t lds, int grid, hipStream_t s, const unsigned cha
             const Tables& tb, const Geom& g, int ngroups, int ao) {
     allow_lds(k_p0_fwd_pers<T, LOG2M, LG, MAXT>, lds);
     hipLaunchKernelGGL((k_p0_fwd_pers<T, LOG2M, LG, MAXT>), dim3(grid), dim3(threads), lds, s, pcm, pay, am,
-                       static_cast<const cx<T>*>(tb.tw), static_cast<const cx<T>*>(tb.post), g, ngroups, ao);
+                       static_cast<const cx<T>*>(tb.blob), g, ngroups, ao);
 }
 
 template <int BITS>
 void go_inv(int cc, int threads, size_t lds, int grid, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb,
             const Geom& g, int ngroups) {
-    const cx<double>* tw = static_cast<const cx<double>*>(tb.tw);
-    const cx<double>* post = static_cast<const cx<double>*>(tb.post);
+    const cx<double>* blob = static_cast<const cx<double>*>(tb.blob);
     if (cc == 2) {
         allow_lds(k_p0_inv_pers<10, BITS, 2, 512>, lds);
-        hipLaunchKernelGGL((k_p0_inv_pers<10, BITS, 2, 512>), dim3(grid), dim3(threads), lds, s, pay, out, tw, post, g, ngroups);
+        hipLaunchKernelGGL((k_p0_inv_pers<10, BITS, 2, 512>), dim3(grid), dim3(threads), lds, s, pay, out, blob, g, ngroups);
     } else {
         allow_lds(k_p0_inv_pers<10, BITS, 1, 512>, lds);
-        hipLaunchKernelGGL((k_p0_inv_pers<10, BITS, 1, 512>), dim3(grid), dim3(threads), lds, s, pay, out, tw, post, g, ngroups);
+        hipLaunchKernelGGL((k_p0_inv_pers<10, BITS, 1, 512>), dim3(grid), dim3(threads), lds, s, pay, out, blob, g, ngroups);
     }
 }
 
 }  // namespace
 
+// Host image of the LDS table blob (PersLayout<LOG2M>): pass tables in lane-linear order, then w_k, g_k.
+// `unit(p, q, re, im)` must return exp(-i pi p / q).
+template <typename T, int LOG2M>
+static void fill_blob(std::vector<cx<T>>& out, void (*unit)(long long, long long, long double&, long double&)) {
+    using L = PersLayout<LOG2M>; using P = PersPlan<LOG2M>;
+    constexpr int M = 1 << LOG2M, N = 2 * M, TEAM = Plan<LOG2M>::TEAM;
+    out.assign(L::SLOTS, cx<T>{0, 0});
+    auto pass = [&](int off, int R, int NS) {
+        const int NB = M / R / TEAM, KW = NS > TEAM ? TEAM : NS, nbn = NS > TEAM ? NB : 1;
+        for (int nb = 0; nb < nbn; ++nb)
+            for (int j = 1; j < R; ++j)
+                for (int kk = 0; kk < KW; ++kk) {
+                    const long long k = (kk + (long long)nb * TEAM) & (NS - 1);
+                    long double re, im; unit(2 * j * k, (long long)NS * R, re, im);      // W_{NS R}^{j k}
+                    out[off + (nb * (R - 1) + (j - 1)) * KW + kk] = cx<T>{(T)re, (T)im};
+                }
+    };
+    pass(L::OFF2, P::R2, P::NS2);
+    pass(L::OFF3, P::R3, P::NS3);
+    for (int k = 0; k <= M / 2; ++k) {
+        long double re, im;
+        unit(k, 2LL * N, re, im); out[L::OFFP + k] = cx<T>{(T)re, (T)im};
+        unit((long long)N + 5LL * k, 2LL * N, re, im); out[L::OFFP + M / 2 + 1 + k] = cx<T>{(T)re, (T)im};
+    }
+}
+// bytes of the blob for (log2m, f32), 0 when the plan has no persistent kernel
+size_t pers_blob_build(int log2m, bool f32, std::vector<unsigned char>& bytes,
+                       void (*unit)(long long, long long, long double&, long double&)) {
+    bytes.clear();
+    if (log2m == 10 && !f32) { std::vector<cx<double>> v; fill_blob<double, 10>(v, unit); bytes.assign((unsigned char*)v.data(), (unsigned char*)(v.data() + v.size())); }
+    else if (log2m == 11 && f32) { std::vector<cx<float>> v; fill_blob<float, 11>(v, unit); bytes.assign((unsigned char*)v.data(), (unsigned char*)(v.data() + v.size())); }
+    return bytes.size();
+}
+
 // returns 1 when the persistent kernel took the launch, 0 when the geometry is not one of its own
 int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const unsigned char* pcm, unsigned char* pay,
                        double* am, const Tables& tb, Geom g, int ao) {
-    if (disabled() || c.cg != g.C || g.in_mode == 0 || g.n_valid != g.N || g.C > 8) return 0;
+    if (disabled() || tb.blob == nullptr || c.cg != g.C || g.in_mode == 0 || g.n_valid != g.N || g.C > 8) return 0;
     const bool geom_ok = f32 ? (c.log2m == 11 && lg == 2) : (c.log2m == 10 && lg >= 1 && lg <= 3);
     if (!geom_ok) return 0;
     const int team = c.team, M = 1 << c.log2m;
@@ -69,7 +103,7 @@ int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const 
 }
 
 int launch_p0_inv_pers(const FastCfg& c, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb, Geom g) {
-    if (disabled() || c.cg != g.C || c.log2m != 10 || g.C > 2 || g.cc_fast != g.C || g.in_mode != g.C) return 0;
+    if (disabled() || tb.blob == nullptr || c.cg != g.C || c.log2m != 10 || g.C > 2 || g.cc_fast != g.C || g.in_mode != g.C) return 0;
     const int teams = 8;
     g.fpb = teams / g.C;
     const int threads = teams * c.team;

@@ -17,21 +17,40 @@
 
 namespace frad {
 
-// highest twiddle index any pass of the plan reads, plus one (rounded up to 8)
+// LDS table blob of a plan (units: complex slots): [pass-2 table][pass-3 table][w_k][g_k]
 template <int LOG2M> struct PersPlan;
-template <> struct PersPlan<10> { static constexpr int TWN = 904; };    // 16 16 4 : 15*15*4 = 900
-template <> struct PersPlan<11> { static constexpr int TWN = 1808; };   // 16 16 8 : 15*15*8 = 1800
-
+template <> struct PersPlan<10> {                       // M = 1024, TEAM = 64 : 16 16 4
+    static constexpr int R2 = 16, NS2 = 16, R3 = 4, NS3 = 256;
+};
+template <> struct PersPlan<11> {                       // M = 2048, TEAM = 128 : 16 16 8
+    static constexpr int R2 = 16, NS2 = 16, R3 = 8, NS3 = 256;
+};
+template <int LOG2M> struct PersLayout {
+    static constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM;
+    using P = PersPlan<LOG2M>;
+    static constexpr int OFF2 = 0;
+    static constexpr int OFF3 = OFF2 + pass_table_size<TEAM, P::R2, P::NS2, M>();
+    static constexpr int OFFP = OFF3 + pass_table_size<TEAM, P::R3, P::NS3, M>();
+    static constexpr int SLOTS = OFFP + 2 * (M / 2 + 1);
+};
 template <typename T, int LOG2M> __host__ __device__ constexpr int pers_table_bytes() {
-    return (PersPlan<LOG2M>::TWN + 2 * ((1 << LOG2M) / 2 + 1)) * (int)sizeof(cx<T>);
+    return ((PersLayout<LOG2M>::SLOTS * (int)sizeof(cx<T>) + 15) / 16) * 16;
 }
 
 template <typename T, int LOG2M>
-__device__ __forceinline__ void pers_load_tables(unsigned char* smem, const cx<T>* __restrict__ tw, const cx<T>* __restrict__ post) {
-    constexpr int TWN = PersPlan<LOG2M>::TWN, POSTN = 2 * ((1 << LOG2M) / 2 + 1);
-    cx<T>* ltw = reinterpret_cast<cx<T>*>(smem);
-    for (int i = threadIdx.x; i < TWN; i += blockDim.x) ltw[i] = tw[i];
-    for (int i = threadIdx.x; i < POSTN; i += blockDim.x) ltw[TWN + i] = post[i];
+__device__ __forceinline__ void pers_load_tables(unsigned char* smem, const cx<T>* __restrict__ blob) {
+    cx<T>* l = reinterpret_cast<cx<T>*>(smem);
+    for (int i = threadIdx.x; i < PersLayout<LOG2M>::SLOTS; i += blockDim.x) l[i] = blob[i];
+}
+
+// forward / inverse transform of one channel-frame with every table in LDS
+template <typename T, int LOG2M, bool INV>
+__device__ __forceinline__ void fft_team_lt(cx<T>* buf, int t, const cx<T>* ltab) {
+    constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM, SH = Plan<LOG2M>::SH;
+    using P = PersPlan<LOG2M>; using L = PersLayout<LOG2M>;
+    fft_pass_lt<T, M, TEAM, 16, 1, INV, SH>(buf, t, ltab);
+    fft_pass_lt<T, M, TEAM, P::R2, P::NS2, INV, SH>(buf, t, ltab + L::OFF2);
+    fft_pass_lt<T, M, TEAM, P::R3, P::NS3, INV, SH>(buf, t, ltab + L::OFF3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -41,16 +60,16 @@ __device__ __forceinline__ void pers_load_tables(unsigned char* smem, const cx<T
 template <typename T, int LOG2M, int LG, int MAXT>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 2 : 1))
 k_p0_fwd_pers(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload, double* absmax,
-              const cx<T>* __restrict__ tw, const cx<T>* __restrict__ post, Geom g, int ngroups, int aligned_out) {
+              const cx<T>* __restrict__ blob, Geom g, int ngroups, int aligned_out) {
     constexpr int M = 1 << LOG2M, N = 2 * M, TEAM = Plan<LOG2M>::TEAM, SH = Plan<LOG2M>::SH;
     constexpr int TB = pers_table_bytes<T, LOG2M>();
     constexpr int CPT = (N << LG) / (16 * TEAM);
     constexpr int EPC = 16 >> LG;
     static_assert(CPT >= 1 && CPT * 16 * TEAM == (N << LG), "chunks per thread");
     FRAD_DYN_SMEM(smem);
-    pers_load_tables<T, LOG2M>(smem, tw, post);
-    const cx<T>* ltw = reinterpret_cast<const cx<T>*>(smem);
-    const cx<T>* lpost = ltw + PersPlan<LOG2M>::TWN;
+    pers_load_tables<T, LOG2M>(smem, blob);
+    const cx<T>* ltab = reinterpret_cast<const cx<T>*>(smem);
+    const cx<T>* lpost = ltab + PersLayout<LOG2M>::OFFP;
     unsigned char* data = smem + TB;
     const int C = g.C, fpb = g.fpb, mode = g.in_mode;
     const int cf = threadIdx.x / TEAM, t0 = threadIdx.x - cf * TEAM;
@@ -170,19 +189,25 @@ k_p0_fwd_pers(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         const int nfl = rem < fpb ? (int)rem : fpb;
         tid = threadIdx.x; FRAD_OPAQUE(tid);                  // no hoisting of per-lane addresses out of the loop
         stage_write(nfl);
-        __syncthreads();
+        FRAD_LDS_BARRIER();
         const long long next = grp + gridDim.x;
         if (next < ngroups) prefetch(next);                   // in flight during the butterflies
         int t = t0, cfo = cf * M;
         FRAD_OPAQUE(t); FRAD_OPAQUE(cfo);                     // recompute LDS addresses per iteration (no LICM)
         cx<T>* buf = reinterpret_cast<cx<T>*>(data) + cfo;
-        fft_team<T, LOG2M, false>(buf, t, ltw);
-        dct_post<T, LOG2M>(buf, t, lpost);
-        __syncthreads();
+        fft_team_lt<T, LOG2M, false>(buf, t, ltab);
+        dct_post<T, LOG2M, 1>(buf, t, lpost);
+        // retire the prefetch here (it had the whole transform to land; last iteration's stores are
+        // long done too), so that the wait for it does not end up behind this iteration's stores
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) FRAD_OPAQUE(pf[i][j]);
+        FRAD_LDS_BARRIER();
         if (g.cc_fast == 2) pack_out_pairs_any<T, SH, 2>(TB, payload, absmax, g, f0, nfl, M);
         else if (g.cc_fast == 1) pack_out_pairs_any<T, SH, 1>(TB, payload, absmax, g, f0, nfl, M);
         else pack_out_any<T, SH>(TB, payload, absmax, g, f0, nfl, M, aligned_out != 0);
-        __syncthreads();
+        FRAD_LDS_BARRIER();
         grp = next;
     }
 }
@@ -193,7 +218,7 @@ k_p0_fwd_pers(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
 template <int LOG2M, int BITS, int CC, int MAXT>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 2 : 1))
 k_p0_inv_pers(const unsigned char* __restrict__ payload, double* __restrict__ out,
-              const cx<double>* __restrict__ tw, const cx<double>* __restrict__ post, Geom g, int ngroups) {
+              const cx<double>* __restrict__ blob, Geom g, int ngroups) {
     constexpr int M = 1 << LOG2M, N = 2 * M, TEAM = Plan<LOG2M>::TEAM, SH = Plan<LOG2M>::SH;
     constexpr int TB = pers_table_bytes<double, LOG2M>();
     constexpr int U = unit_values(BITS), UB = unit_bytes(BITS);
@@ -201,9 +226,9 @@ k_p0_inv_pers(const unsigned char* __restrict__ payload, double* __restrict__ ou
     constexpr int TPT = N / (V * TEAM);                       // tasks per thread and iteration
     static_assert(TPT >= 1 && TPT * V * TEAM == N, "tasks per thread");
     FRAD_DYN_SMEM(smem);
-    pers_load_tables<double, LOG2M>(smem, tw, post);
-    const cx<double>* ltw = reinterpret_cast<const cx<double>*>(smem);
-    const cx<double>* lpost = ltw + PersPlan<LOG2M>::TWN;
+    pers_load_tables<double, LOG2M>(smem, blob);
+    const cx<double>* ltab = reinterpret_cast<const cx<double>*>(smem);
+    const cx<double>* lpost = ltab + PersLayout<LOG2M>::OFFP;
     unsigned char* data = smem + TB;
     const int fpb = g.fpb;
     const bool le = g.le && (BITS % 8 == 0);
@@ -262,17 +287,23 @@ k_p0_inv_pers(const unsigned char* __restrict__ payload, double* __restrict__ ou
         const int nfl = rem < fpb ? (int)rem : fpb;
         tid = threadIdx.x; FRAD_OPAQUE(tid);
         stage_write(nfl);
-        __syncthreads();
+        FRAD_LDS_BARRIER();
         const long long next = grp + gridDim.x;
         if (next < ngroups) prefetch(next);
         int t = t0, cfo = cf * M;
         FRAD_OPAQUE(t); FRAD_OPAQUE(cfo);
         cx<double>* buf = reinterpret_cast<cx<double>*>(data) + cfo;
-        dct_pre_inverse<double, LOG2M>(buf, t, lpost);
-        fft_team<double, LOG2M, true>(buf, t, ltw);
-        __syncthreads();
+        dct_pre_inverse<double, LOG2M, 1>(buf, t, lpost);
+        fft_team_lt<double, LOG2M, true>(buf, t, ltab);
+#pragma unroll
+        for (int i = 0; i < TPT; ++i)
+#pragma unroll
+            for (int w = 0; w < UPV; ++w)
+#pragma unroll
+                for (int j = 0; j < UB / 4; ++j) FRAD_OPAQUE(pf[i][w][j]);
+        FRAD_LDS_BARRIER();
         store_pcm_quads<SH, CC>(TB, out, g, f0, nfl, M);
-        __syncthreads();
+        FRAD_LDS_BARRIER();
         grp = next;
     }
 }

@@ -16,5 +16,8 @@
 // make a lane value opaque to the optimiser (used to stop loop-invariant code motion from parking
 // hundreds of per-lane LDS addresses in VGPRs across a persistent loop)
 #define FRAD_OPAQUE(x) asm volatile("" : "+v"(x))
+// workgroup barrier that only waits for this wave's LDS traffic: __syncthreads() also drains vmcnt,
+// i.e. every global load and store in flight, which is exactly what a pipelined kernel must not do
+#define FRAD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 #include <stdint.h>

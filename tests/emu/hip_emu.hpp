@@ -63,6 +63,7 @@ template <typename F> void launch(dim3 grid, dim3 block, size_t lds, F&& body) {
 #define gridDim emu::g_dim
 #define FRAD_DYN_SMEM(name) unsigned char* name = emu::smem_base()
 #define FRAD_OPAQUE(x) asm volatile("" : "+r"(x))
+#define FRAD_LDS_BARRIER() __syncthreads()
 
 inline void __syncthreads() { emu::blk->bar.arrive_and_wait(); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
