@@ -83,6 +83,58 @@ __device__ __forceinline__ T cvt_pcm(u64 raw, int code, bool raw_be_ints) {
     return (T)v;
 }
 
+// The same conversion with the format known at compile time (CODE = FRAD_PCM_* value, RAW = the
+// big-endian-integer quirk): branch-free, a handful of VALU ops per element.  Kernels pick the
+// instantiation once per stage through dispatch_pcm() instead of branching per element.
+template <typename T, int CODE, bool RAW>
+__device__ __forceinline__ T cvt_pcm_c(u64 raw) {
+    constexpr int kind = CODE >> 3, lg = (CODE >> 1) & 3, be = CODE & 1;
+    if constexpr (be) {
+        if constexpr (lg == 1) raw = bswap16((uint32_t)raw);
+        else if constexpr (lg == 2) raw = bswap32((uint32_t)raw);
+        else if constexpr (lg == 3) raw = bswap64(raw);
+    }
+    if constexpr (kind == 2) {
+        if constexpr (lg == 1) return (T)f16_bits_to_f32((uint32_t)raw);
+        else if constexpr (lg == 2) return (T)u2f((uint32_t)raw);
+        else return (T)u2d(raw);
+    } else {
+        constexpr int w = 8 << lg;
+        double v;
+        if constexpr (kind == 1) {
+            if constexpr (lg <= 2) v = (double)((int)((uint32_t)raw << (32 - w)) >> (32 - w));
+            else v = (double)(long long)raw;
+        } else {
+            if constexpr (lg <= 2) v = (double)(uint32_t)raw;
+            else v = (double)raw;
+        }
+        if constexpr (be && RAW) return (T)v;
+        v = v * u2d((u64)(1023 - (w - 1)) << 52);
+        if constexpr (kind == 0) v = v - 1.0;
+        return (T)v;
+    }
+}
+
+template <int V> struct ic { static constexpr int value = V; };
+// f(ic<CODE>{}, ic<RAW>{}) for the runtime (dtype, raw_be) pair; LG fixes the item size.
+template <int LG, typename F>
+__device__ __forceinline__ void dispatch_pcm(int dtype, int raw_be, F&& f) {
+    const int kind = dtype >> 3, be = dtype & 1;
+    if (kind == 2) {
+        if constexpr (LG >= 1) { if (be) f(ic<16 + LG * 2 + 1>{}, ic<0>{}); else f(ic<16 + LG * 2>{}, ic<0>{}); }
+    } else if (kind == 1) {
+        if constexpr (LG >= 1) {
+            if (be) { if (raw_be) f(ic<8 + LG * 2 + 1>{}, ic<1>{}); else f(ic<8 + LG * 2 + 1>{}, ic<0>{}); }
+            else f(ic<8 + LG * 2>{}, ic<0>{});
+        } else f(ic<8>{}, ic<0>{});
+    } else {
+        if constexpr (LG >= 1) {
+            if (be) { if (raw_be) f(ic<LG * 2 + 1>{}, ic<1>{}); else f(ic<LG * 2 + 1>{}, ic<0>{}); }
+            else f(ic<LG * 2>{}, ic<0>{});
+        } else f(ic<0>{}, ic<0>{});
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // storage codes.  code = the `bits` stored bits of one value, right-aligned, MSB-first order.
 // ---------------------------------------------------------------------------------------------

@@ -113,11 +113,13 @@ template <int R, bool INV, typename T> __device__ __forceinline__ void dft(cx<T>
 
 // team-level synchronisation: lanes of one wave run in lockstep and the LDS serves a wave's
 // instructions in order, so a team that fits in a wave only needs the compiler kept honest.
-template <int TEAM> __device__ __forceinline__ void team_sync() {
+template <int TEAM, bool LDSONLY = false> __device__ __forceinline__ void team_sync() {
     if constexpr (TEAM <= 64) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else if constexpr (LDSONLY) {
+        FRAD_LDS_BARRIER();                      // pipelined kernels: do not drain global loads/stores
     } else {
         __syncthreads();
     }
@@ -187,7 +189,7 @@ __device__ __forceinline__ void fft_pass_lt(cx<T>* buf, int t, const cx<T>* ptab
 #pragma unroll
         for (int j = 0; j < R; ++j) v[nb][j] = buf[phys<T, SH>(b + j * (M / R))];
     }
-    team_sync<TEAM>();
+    team_sync<TEAM, true>();
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int b = t + nb * TEAM;
@@ -206,7 +208,7 @@ __device__ __forceinline__ void fft_pass_lt(cx<T>* buf, int t, const cx<T>* ptab
 #pragma unroll
         for (int j = 0; j < R; ++j) buf[phys<T, SH>(base + j * NS)] = v[nb][j];
     }
-    team_sync<TEAM>();
+    team_sync<TEAM, true>();
 }
 
 // Pass schedules.  P = points per lane = max radix, TEAM = M / P lanes per channel-frame.
@@ -264,10 +266,10 @@ __device__ __forceinline__ int makhoul(int n, int N) { return (n & 1) ? N - 1 - 
 // post[k] = { w_k, g_k } with w_k = exp(-i pi k / 2N), g_k = -i w_k exp(-2 pi i k / N), k in [0, M/2]
 //
 // forward: Z (FFT of the packed sequence) -> X[k] = (1/N) sum x[n] cos(pi k (2n+1) / 2N), in place.
-template <typename T, int LOG2M, int PS = 2>
+template <typename T, int LOG2M, int PS = 2, int TEAM = Plan<LOG2M>::TEAM, int SH = Plan<LOG2M>::SH, bool LDSONLY = false>
 __device__ __forceinline__ void dct_post(cx<T>* buf, int t, const cx<T>* __restrict__ post) {
     constexpr int GOFF = PS == 2 ? 1 : (1 << LOG2M) / 2 + 1;   // where g_k lives relative to w_k
-    constexpr int M = 1 << LOG2M, N = 2 * M, TEAM = Plan<LOG2M>::TEAM, SH = Plan<LOG2M>::SH;
+    constexpr int M = 1 << LOG2M, N = 2 * M;
     constexpr int PP = (M / 2) / TEAM;         // pairs per lane (pair M/2 goes to lane 0 on top)
     constexpr T sc = (T)1 / (T)(2 * N);
     constexpr T sc2 = K<T>::s2 / (T)(2 * N);
@@ -281,7 +283,7 @@ __device__ __forceinline__ void dct_post(cx<T>* buf, int t, const cx<T>* __restr
         const cx<T> p = cmul(zk + zp, post[PS * k]), q = cmul(zk - zp, post[PS * k + GOFF]);
         S[i] = p + q; D[i] = p - q;
     }
-    team_sync<TEAM>();
+    team_sync<TEAM, LDSONLY>();
 #pragma unroll
     for (int i = 0; i <= PP; ++i) {
         const int k = (i < PP) ? t + i * TEAM : M / 2;
@@ -293,15 +295,15 @@ __device__ __forceinline__ void dct_post(cx<T>* buf, int t, const cx<T>* __restr
             if (k > 0) real_slot<T, SH>(buf, M + k) = (D[i].x + D[i].y) * sc2;
         }
     }
-    team_sync<TEAM>();
+    team_sync<TEAM, LDSONLY>();
 }
 
 // inverse: X (N reals, 'forward'-normalised DCT-II coefficients) -> Z' = Z / M, in place, so that
 // the unscaled inverse FFT returns the packed time sequence.
-template <typename T, int LOG2M, int PS = 2>
+template <typename T, int LOG2M, int PS = 2, int TEAM = Plan<LOG2M>::TEAM, int SH = Plan<LOG2M>::SH, bool LDSONLY = false>
 __device__ __forceinline__ void dct_pre_inverse(cx<T>* buf, int t, const cx<T>* __restrict__ post) {
     constexpr int GOFF = PS == 2 ? 1 : (1 << LOG2M) / 2 + 1;
-    constexpr int M = 1 << LOG2M, N = 2 * M, TEAM = Plan<LOG2M>::TEAM, SH = Plan<LOG2M>::SH;
+    constexpr int M = 1 << LOG2M, N = 2 * M;
     constexpr int PP = (M / 2) / TEAM;
     cx<T> A[PP + 1], B[PP + 1];
     __builtin_amdgcn_sched_barrier(0);
@@ -317,7 +319,7 @@ __device__ __forceinline__ void dct_pre_inverse(cx<T>* buf, int t, const cx<T>* 
         A[i] = cmul(u + s, conj(post[PS * k]));
         B[i] = cmul(u - s, conj(post[PS * k + GOFF]));
     }
-    team_sync<TEAM>();
+    team_sync<TEAM, LDSONLY>();
 #pragma unroll
     for (int i = 0; i <= PP; ++i) {
         const int k = (i < PP) ? t + i * TEAM : M / 2;
@@ -325,7 +327,7 @@ __device__ __forceinline__ void dct_pre_inverse(cx<T>* buf, int t, const cx<T>* 
         buf[phys<T, SH>(k)] = A[i] + B[i];
         if (k > 0 && k < M / 2) buf[phys<T, SH>(M - k)] = conj(A[i] - B[i]);
     }
-    team_sync<TEAM>();
+    team_sync<TEAM, LDSONLY>();
 }
 
 }  // namespace frad

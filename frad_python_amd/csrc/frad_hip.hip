@@ -75,9 +75,11 @@ int build_tables(int log2m, Tables& out) {
     HIPCHK(hipMemcpy(out.tw, tw.data(), tw.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(out.post, post.data(), post.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
     std::vector<unsigned char> blob;
-    if (pers_blob_build(log2m, sizeof(T) == 4, blob, unit_neg)) {
-        HIPCHK(hipMalloc(&out.blob, blob.size()));
-        HIPCHK(hipMemcpy(out.blob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    for (int which = 0; which < 2; ++which) {
+        if (!pers_blob_build(log2m, sizeof(T) == 4, which, blob, unit_neg)) continue;
+        void*& dst = which ? out.blob_b : out.blob;
+        HIPCHK(hipMalloc(&dst, blob.size()));
+        HIPCHK(hipMemcpy(dst, blob.data(), blob.size(), hipMemcpyHostToDevice));
     }
     return FRAD_OK;
 }
@@ -229,7 +231,7 @@ int frad_plan_prepare(int32_t N, int32_t compute_f32) {
 
 void frad_plan_clear(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (auto& kv : g_tables) { (void)hipFree(kv.second.tw); (void)hipFree(kv.second.post); if (kv.second.blob) (void)hipFree(kv.second.blob); }
+    for (auto& kv : g_tables) { (void)hipFree(kv.second.tw); (void)hipFree(kv.second.post); if (kv.second.blob) (void)hipFree(kv.second.blob); if (kv.second.blob_b) (void)hipFree(kv.second.blob_b); }
     for (auto& kv : g_direct) (void)hipFree(kv.second.ct);
     g_tables.clear(); g_direct.clear();
 }

@@ -7,7 +7,7 @@
 
 namespace frad {
 
-struct Tables { void* tw = nullptr; void* post = nullptr; void* blob = nullptr; };   // blob: LDS image of the persistent kernels
+struct Tables { void* tw = nullptr; void* post = nullptr; void* blob = nullptr; void* blob_b = nullptr; };   // blob: LDS image of the persistent kernels
 
 // launch geometry of the LDS-resident FFT kernels
 struct FastCfg {
@@ -31,7 +31,7 @@ int launch_p0_fwd_f32(int lg, const FastCfg& c, dim3 grid, hipStream_t s, const 
 int launch_p0_inv(const FastCfg& c, dim3 grid, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb,
                   const Geom& g, int aligned_in);
 
-size_t pers_blob_build(int log2m, bool f32, std::vector<unsigned char>& bytes,
+size_t pers_blob_build(int log2m, bool f32, int which, std::vector<unsigned char>& bytes,
                        void (*unit)(long long, long long, long double&, long double&));
 // persistent kernels (frad_p0_pers.hip): return 1 when they took the launch, 0 when not applicable
 int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const unsigned char* pcm, unsigned char* pay,

@@ -17,59 +17,60 @@
 
 namespace frad {
 
-// LDS table blob of a plan (units: complex slots): [pass-2 table][pass-3 table][w_k][g_k]
-template <int LOG2M> struct PersPlan;
-template <> struct PersPlan<10> {                       // M = 1024, TEAM = 64 : 16 16 4
-    static constexpr int R2 = 16, NS2 = 16, R3 = 4, NS3 = 256;
-};
-template <> struct PersPlan<11> {                       // M = 2048, TEAM = 128 : 16 16 8
-    static constexpr int R2 = 16, NS2 = 16, R3 = 8, NS3 = 256;
-};
-template <int LOG2M> struct PersLayout {
-    static constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM;
-    using P = PersPlan<LOG2M>;
+// Plans of the persistent kernels: radices R1..R4 (0 = no such pass), lanes per channel-frame,
+// swizzle shift (log2 R1).
+struct PlanA10 { static constexpr int LOG2M = 10, TEAM = 64,  SH = 4, R1 = 16, R2 = 16, R3 = 4, R4 = 0; };  // 2 waves/SIMD
+struct PlanB10 { static constexpr int LOG2M = 10, TEAM = 128, SH = 3, R1 = 8,  R2 = 8,  R3 = 8, R4 = 2; };  // 4 waves/SIMD
+struct PlanA11 { static constexpr int LOG2M = 11, TEAM = 128, SH = 4, R1 = 16, R2 = 16, R3 = 8, R4 = 0; };
+
+// LDS table blob of a plan (units: complex slots): [pass-2][pass-3][pass-4 tables][w_k][g_k]
+template <typename PL> struct PersLayout {
+    static constexpr int M = 1 << PL::LOG2M, TEAM = PL::TEAM;
+    static constexpr int NS2 = PL::R1, NS3 = PL::R1 * PL::R2, NS4 = PL::R1 * PL::R2 * PL::R3;
     static constexpr int OFF2 = 0;
-    static constexpr int OFF3 = OFF2 + pass_table_size<TEAM, P::R2, P::NS2, M>();
-    static constexpr int OFFP = OFF3 + pass_table_size<TEAM, P::R3, P::NS3, M>();
+    static constexpr int OFF3 = OFF2 + pass_table_size<TEAM, PL::R2, NS2, M>();
+    static constexpr int OFF4 = OFF3 + pass_table_size<TEAM, PL::R3, NS3, M>();
+    static constexpr int OFFP = OFF4 + (PL::R4 ? pass_table_size<TEAM, (PL::R4 ? PL::R4 : 2), NS4, M>() : 0);
     static constexpr int SLOTS = OFFP + 2 * (M / 2 + 1);
 };
-template <typename T, int LOG2M> __host__ __device__ constexpr int pers_table_bytes() {
-    return ((PersLayout<LOG2M>::SLOTS * (int)sizeof(cx<T>) + 15) / 16) * 16;
+template <typename T, typename PL> __host__ __device__ constexpr int pers_table_bytes() {
+    return ((PersLayout<PL>::SLOTS * (int)sizeof(cx<T>) + 15) / 16) * 16;
 }
 
-template <typename T, int LOG2M>
+template <typename T, typename PL>
 __device__ __forceinline__ void pers_load_tables(unsigned char* smem, const cx<T>* __restrict__ blob) {
     cx<T>* l = reinterpret_cast<cx<T>*>(smem);
-    for (int i = threadIdx.x; i < PersLayout<LOG2M>::SLOTS; i += blockDim.x) l[i] = blob[i];
+    for (int i = threadIdx.x; i < PersLayout<PL>::SLOTS; i += blockDim.x) l[i] = blob[i];
 }
 
 // forward / inverse transform of one channel-frame with every table in LDS
-template <typename T, int LOG2M, bool INV>
+template <typename T, typename PL, bool INV>
 __device__ __forceinline__ void fft_team_lt(cx<T>* buf, int t, const cx<T>* ltab) {
-    constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM, SH = Plan<LOG2M>::SH;
-    using P = PersPlan<LOG2M>; using L = PersLayout<LOG2M>;
-    fft_pass_lt<T, M, TEAM, 16, 1, INV, SH>(buf, t, ltab);
-    fft_pass_lt<T, M, TEAM, P::R2, P::NS2, INV, SH>(buf, t, ltab + L::OFF2);
-    fft_pass_lt<T, M, TEAM, P::R3, P::NS3, INV, SH>(buf, t, ltab + L::OFF3);
+    constexpr int M = 1 << PL::LOG2M, TEAM = PL::TEAM, SH = PL::SH;
+    using L = PersLayout<PL>;
+    fft_pass_lt<T, M, TEAM, PL::R1, 1, INV, SH>(buf, t, ltab);
+    fft_pass_lt<T, M, TEAM, PL::R2, L::NS2, INV, SH>(buf, t, ltab + L::OFF2);
+    fft_pass_lt<T, M, TEAM, PL::R3, L::NS3, INV, SH>(buf, t, ltab + L::OFF3);
+    if constexpr (PL::R4 != 0) fft_pass_lt<T, M, TEAM, PL::R4, L::NS4, INV, SH>(buf, t, ltab + L::OFF4);
 }
 
 // ---------------------------------------------------------------------------------------------
 // encode.  grid = min(groups, CUs); block = teams * TEAM threads, teams = fpb * C (<= 8).
 // Per iteration a thread stages CPT = N * itemsize / (16 * TEAM) 16-byte chunks of PCM.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int LOG2M, int LG, int MAXT>
+template <typename T, typename PL, int LG, int MAXT>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 2 : 1))
 k_p0_fwd_pers(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload, double* absmax,
               const cx<T>* __restrict__ blob, Geom g, int ngroups, int aligned_out) {
-    constexpr int M = 1 << LOG2M, N = 2 * M, TEAM = Plan<LOG2M>::TEAM, SH = Plan<LOG2M>::SH;
-    constexpr int TB = pers_table_bytes<T, LOG2M>();
+    constexpr int LOG2M = PL::LOG2M, M = 1 << LOG2M, N = 2 * M, TEAM = PL::TEAM, SH = PL::SH;
+    constexpr int TB = pers_table_bytes<T, PL>();
     constexpr int CPT = (N << LG) / (16 * TEAM);
     constexpr int EPC = 16 >> LG;
     static_assert(CPT >= 1 && CPT * 16 * TEAM == (N << LG), "chunks per thread");
     FRAD_DYN_SMEM(smem);
-    pers_load_tables<T, LOG2M>(smem, blob);
+    pers_load_tables<T, PL>(smem, blob);
     const cx<T>* ltab = reinterpret_cast<const cx<T>*>(smem);
-    const cx<T>* lpost = ltab + PersLayout<LOG2M>::OFFP;
+    const cx<T>* lpost = ltab + PersLayout<PL>::OFFP;
     unsigned char* data = smem + TB;
     const int C = g.C, fpb = g.fpb, mode = g.in_mode;
     const int cf = threadIdx.x / TEAM, t0 = threadIdx.x - cf * TEAM;
@@ -102,9 +103,10 @@ k_p0_fwd_pers(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         const long long rem = g.n_frames - f0;
         const int nfl = rem < fpb ? (int)rem : fpb;
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
+        for (int i = 0; i < CPT; ++i) {          // unconditional: a missing frame re-reads the last live one
             int fl, ch; locate(i, fl, ch);
-            if (fl < nfl) load_words<4>(pcm + (f0 + fl) * frameb + (long long)ch * 16, pf[i]);
+            fl = fl < nfl ? fl : nfl - 1;
+            load_words<4>(pcm + (f0 + fl) * frameb + (long long)ch * 16, pf[i]);
         }
     };
     auto put = [&](int fl, int c, int zq, T e0, T e1, T e2, T e3) {
@@ -112,7 +114,9 @@ k_p0_fwd_pers(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         b[phys<T, SH>(zq)] = cx<T>{e0, e2};
         b[phys<T, SH>(M - 1 - zq)] = cx<T>{e3, e1};
     };
-    auto stage_write = [&](int nfl) {
+    auto stage_write_c = [&](int nfl, auto code_tag, auto raw_tag) {
+        constexpr int CODE = decltype(code_tag)::value;
+        constexpr bool RAW = decltype(raw_tag)::value != 0;
         if (mode == 3) {
             if constexpr (CPT % 4 == 0) {
 #pragma unroll
@@ -125,7 +129,7 @@ k_p0_fwd_pers(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
                     for (int e = 0; e < EPC; ++e) {
                         T v[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = cvt_pcm<T>(word_elem<LG>(pf[4 * k + i], e), g.dtype, g.raw_be);
+                        for (int i = 0; i < 4; ++i) v[i] = cvt_pcm_c<T, CODE, RAW>(word_elem<LG>(pf[4 * k + i], e));
                         put(fl, sl * EPC + e, zq, v[0], v[1], v[2], v[3]);
                     }
                 }
@@ -144,7 +148,7 @@ k_p0_fwd_pers(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int idx = i * CC + c;                      // element inside the 32-byte quad
-                            v[i] = cvt_pcm<T>(word_elem<LG>(pf[2 * k + idx / EPC], idx % EPC), g.dtype, g.raw_be);
+                            v[i] = cvt_pcm_c<T, CODE, RAW>(word_elem<LG>(pf[2 * k + idx / EPC], idx % EPC));
                         }
                         put(fl, c, zq, v[0], v[1], v[2], v[3]);
                     }
@@ -166,7 +170,7 @@ k_p0_fwd_pers(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
                                 for (int c = 0; c < CC; ++c) {
                                     T v[4];
 #pragma unroll
-                                    for (int r = 0; r < 4; ++r) v[r] = cvt_pcm<T>(word_elem<LG>(pf[i], (gi * 4 + r) * CC + c), g.dtype, g.raw_be);
+                                    for (int r = 0; r < 4; ++r) v[r] = cvt_pcm_c<T, CODE, RAW>(word_elem<LG>(pf[i], (gi * 4 + r) * CC + c));
                                     put(fl, c, ch * GPC + gi, v[0], v[1], v[2], v[3]);
                                 }
                         }
@@ -179,6 +183,7 @@ k_p0_fwd_pers(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
             }
         }
     };
+    auto stage_write = [&](int nfl) { dispatch_pcm<LG>(g.dtype, g.raw_be, [&](auto c, auto r) { stage_write_c(nfl, c, r); }); };
 
     long long grp = blockIdx.x;
     if (grp < ngroups) prefetch(grp);
@@ -195,8 +200,8 @@ k_p0_fwd_pers(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         int t = t0, cfo = cf * M;
         FRAD_OPAQUE(t); FRAD_OPAQUE(cfo);                     // recompute LDS addresses per iteration (no LICM)
         cx<T>* buf = reinterpret_cast<cx<T>*>(data) + cfo;
-        fft_team_lt<T, LOG2M, false>(buf, t, ltab);
-        dct_post<T, LOG2M, 1>(buf, t, lpost);
+        fft_team_lt<T, PL, false>(buf, t, ltab);
+        dct_post<T, LOG2M, 1, TEAM, SH, true>(buf, t, lpost);
         // retire the prefetch here (it had the whole transform to land; last iteration's stores are
         // long done too), so that the wait for it does not end up behind this iteration's stores
 #pragma unroll
@@ -215,20 +220,20 @@ k_p0_fwd_pers(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
 // ---------------------------------------------------------------------------------------------
 // decode (always float64).  CC = channels (1 or 2), payload side in whole pack units.
 // ---------------------------------------------------------------------------------------------
-template <int LOG2M, int BITS, int CC, int MAXT>
+template <typename PL, int BITS, int CC, int MAXT>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 512 ? 2 : 1))
 k_p0_inv_pers(const unsigned char* __restrict__ payload, double* __restrict__ out,
               const cx<double>* __restrict__ blob, Geom g, int ngroups) {
-    constexpr int M = 1 << LOG2M, N = 2 * M, TEAM = Plan<LOG2M>::TEAM, SH = Plan<LOG2M>::SH;
-    constexpr int TB = pers_table_bytes<double, LOG2M>();
+    constexpr int LOG2M = PL::LOG2M, M = 1 << LOG2M, N = 2 * M, TEAM = PL::TEAM, SH = PL::SH;
+    constexpr int TB = pers_table_bytes<double, PL>();
     constexpr int U = unit_values(BITS), UB = unit_bytes(BITS);
     constexpr int V = U > 2 * CC ? U : 2 * CC, KB = V / CC, UPV = V / U;
     constexpr int TPT = N / (V * TEAM);                       // tasks per thread and iteration
     static_assert(TPT >= 1 && TPT * V * TEAM == N, "tasks per thread");
     FRAD_DYN_SMEM(smem);
-    pers_load_tables<double, LOG2M>(smem, blob);
+    pers_load_tables<double, PL>(smem, blob);
     const cx<double>* ltab = reinterpret_cast<const cx<double>*>(smem);
-    const cx<double>* lpost = ltab + PersLayout<LOG2M>::OFFP;
+    const cx<double>* lpost = ltab + PersLayout<PL>::OFFP;
     unsigned char* data = smem + TB;
     const int fpb = g.fpb;
     const bool le = g.le && (BITS % 8 == 0);
@@ -244,12 +249,12 @@ k_p0_inv_pers(const unsigned char* __restrict__ payload, double* __restrict__ ou
 #pragma unroll
         for (int i = 0; i < TPT; ++i) {
             const int task = tid + i * blockDim.x;
-            const int fl = task / tasks_pf, u = task - fl * tasks_pf;
-            if (fl < nfl) {
-                const unsigned char* src = payload + (f0 + fl) * g.payload_stride;
+            int fl = task / tasks_pf;
+            const int u = task - fl * tasks_pf;
+            fl = fl < nfl ? fl : nfl - 1;                     // unconditional loads: no branch, no early wait
+            const unsigned char* src = payload + (f0 + fl) * g.payload_stride;
 #pragma unroll
-                for (int w = 0; w < UPV; ++w) load_words<UB / 4>(src + ((long long)u * UPV + w) * UB, pf[i][w]);
-            }
+            for (int w = 0; w < UPV; ++w) load_words<UB / 4>(src + ((long long)u * UPV + w) * UB, pf[i][w]);
         }
     };
     auto stage_write = [&](int nfl) {
@@ -293,8 +298,8 @@ k_p0_inv_pers(const unsigned char* __restrict__ payload, double* __restrict__ ou
         int t = t0, cfo = cf * M;
         FRAD_OPAQUE(t); FRAD_OPAQUE(cfo);
         cx<double>* buf = reinterpret_cast<cx<double>*>(data) + cfo;
-        dct_pre_inverse<double, LOG2M, 1>(buf, t, lpost);
-        fft_team_lt<double, LOG2M, true>(buf, t, ltab);
+        dct_pre_inverse<double, LOG2M, 1, TEAM, SH, true>(buf, t, lpost);
+        fft_team_lt<double, PL, true>(buf, t, ltab);
 #pragma unroll
         for (int i = 0; i < TPT; ++i)
 #pragma unroll
