@@ -55,6 +55,31 @@ void go_inv_bits(const void* blob, int cc, int threads, size_t lds, int grid, hi
         default: go_inv<PL, MAXT, 64>(blob, cc, threads, lds, grid, s, pay, out, g, ngroups); break;
     }
 }
+template <int LG>
+void go_fwd_unit(const void* blob, int cc, size_t lds, int grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay,
+                 double* am, const Geom& g) {
+    const cx<double>* b = static_cast<const cx<double>*>(blob);
+    if (cc == 2) {
+        allow_lds(k_p0_fwd_unit<double, PlanA10, LG, 2>, lds);
+        hipLaunchKernelGGL((k_p0_fwd_unit<double, PlanA10, LG, 2>), dim3(grid), dim3(512), lds, s, pcm, pay, am, b, g);
+    } else {
+        allow_lds(k_p0_fwd_unit<double, PlanA10, LG, 1>, lds);
+        hipLaunchKernelGGL((k_p0_fwd_unit<double, PlanA10, LG, 1>), dim3(grid), dim3(512), lds, s, pcm, pay, am, b, g);
+    }
+}
+template <int BITS>
+void go_inv_unit(const void* blob, int cc, size_t lds, int grid, hipStream_t s, const unsigned char* pay, double* out, const Geom& g) {
+    const cx<double>* b = static_cast<const cx<double>*>(blob);
+    if (cc == 2) {
+        allow_lds(k_p0_inv_unit<PlanA10, BITS, 2>, lds);
+        hipLaunchKernelGGL((k_p0_inv_unit<PlanA10, BITS, 2>), dim3(grid), dim3(512), lds, s, pay, out, b, g);
+    } else {
+        allow_lds(k_p0_inv_unit<PlanA10, BITS, 1>, lds);
+        hipLaunchKernelGGL((k_p0_inv_unit<PlanA10, BITS, 1>), dim3(grid), dim3(512), lds, s, pay, out, b, g);
+    }
+}
+bool unit_sync() { const char* e = getenv("FRAD_TUNE_PERS_UNIT"); return !(e && e[0] == '0'); }
+
 // plan of the N = 2048 float64 kernels: B = two waves per channel-frame (4 waves/SIMD), A = one
 bool plan_b() { const char* e = getenv("FRAD_TUNE_PERS_PLAN"); return e && (e[0] == 'B' || e[0] == 'b'); }
 
@@ -103,6 +128,18 @@ int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const 
     if (disabled() || tb.blob == nullptr || c.cg != g.C || g.in_mode == 0 || g.n_valid != g.N || g.C > 8) return 0;
     const bool geom_ok = f32 ? (c.log2m == 11 && lg == 2) : (c.log2m == 10 && lg >= 1 && lg <= 3);
     if (!geom_ok) return 0;
+    if (!f32 && unit_sync() && !plan_b() && g.C <= 2 && g.cc_fast == g.C &&
+        ((g.in_mode == 1) || (g.in_mode == 2 && (8 >> lg) == g.C) || (g.in_mode == 3 && lg >= (g.C == 1 ? 4 : 3)))) {
+        // unit-synchronised kernel: one frame per unit of C waves, 8 / C units per block
+        const int upb = 8 / g.C;
+        const size_t lds = (size_t)pers_table_bytes<double, PlanA10>() + 64 + 8 * 1024 * 16;
+        const long long nb = (g.n_frames + upb - 1) / upb, cap = (long long)cu_count() * blocks_per_cu();
+        const int grid = (int)(nb < cap ? nb : cap);
+        if (lg == 1) go_fwd_unit<1>(tb.blob, g.C, lds, grid, s, pcm, pay, am, g);
+        else if (lg == 2) go_fwd_unit<2>(tb.blob, g.C, lds, grid, s, pcm, pay, am, g);
+        else go_fwd_unit<3>(tb.blob, g.C, lds, grid, s, pcm, pay, am, g);
+        return 1;
+    }
     const bool pb = !f32 && plan_b() && tb.blob_b != nullptr && lg <= 2;
     const int team = f32 ? PlanA11::TEAM : pb ? PlanB10::TEAM : PlanA10::TEAM, M = 1 << c.log2m;
     const int cpt = (int)(((long long)g.N << lg) / (16 * team));
@@ -130,6 +167,21 @@ int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const 
 
 int launch_p0_inv_pers(const FastCfg& c, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb, Geom g) {
     if (disabled() || tb.blob == nullptr || c.cg != g.C || c.log2m != 10 || g.C > 2 || g.cc_fast != g.C || g.in_mode != g.C) return 0;
+    if (unit_sync() && !plan_b()) {
+        const int upb = 8 / g.C;
+        const size_t lds = (size_t)pers_table_bytes<double, PlanA10>() + 64 + 8 * 1024 * 16;
+        const long long nb = (g.n_frames + upb - 1) / upb, cap = (long long)cu_count() * blocks_per_cu();
+        const int grid = (int)(nb < cap ? nb : cap);
+        switch (g.bits) {
+            case 12: go_inv_unit<12>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+            case 16: go_inv_unit<16>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+            case 24: go_inv_unit<24>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+            case 32: go_inv_unit<32>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+            case 48: go_inv_unit<48>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+            default: go_inv_unit<64>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+        }
+        return 1;
+    }
     const bool pb = plan_b() && tb.blob_b != nullptr && g.bits != 12;   // a 12-bit unit is wider than plan B's lane share
     const int teams = 8, team = pb ? PlanB10::TEAM : PlanA10::TEAM;
     g.fpb = teams / g.C;

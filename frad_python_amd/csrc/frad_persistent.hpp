@@ -14,6 +14,9 @@
 #pragma once
 #include "frad_kernels.hpp"
 #include <type_traits>
+#ifdef FRAD_HOST_EMULATION
+#include <thread>
+#endif
 
 namespace frad {
 
@@ -310,6 +313,329 @@ k_p0_inv_pers(const unsigned char* __restrict__ payload, double* __restrict__ ou
         store_pcm_quads<SH, CC>(TB, out, g, f0, nfl, M);
         FRAD_LDS_BARRIER();
         grp = next;
+    }
+}
+
+
+// =============================================================================================
+// Unit-synchronised persistent kernels (C = 1 or 2, plan A).
+//
+// The block-barrier kernels above put all eight waves of a CU in the same phase at the same time:
+// LDS-write-bound staging, then VALU-bound butterflies, then the store burst -- each phase leaves
+// the other pipes idle.  Here the waves of ONE FRAME (CC waves = its channels) form a unit that
+// loops over frames on its own and synchronises only with itself through a tiny LDS counter
+// barrier (the hardware s_barrier is block-wide).  The 8 / CC units of a CU drift apart, so one
+// unit's staging overlaps another's butterflies and a third one's stores, while the 32 KiB of
+// tables in LDS are still shared by all of them.
+// =============================================================================================
+#ifndef FRAD_HOST_EMULATION
+#define FRAD_LDS_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define FRAD_LDS_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define FRAD_NAP() __builtin_amdgcn_s_sleep(1)
+#define FRAD_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define FRAD_LDS_ADD(p, v) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
+#define FRAD_LDS_LOAD(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define FRAD_NAP() std::this_thread::yield()
+#define FRAD_LGKM0() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#endif
+
+// barrier over the NW waves of a unit; `ctr` is the unit's LDS word, `epoch` a per-thread count
+template <int NW> __device__ __forceinline__ void unit_barrier(unsigned* ctr, unsigned& epoch) {
+    if constexpr (NW == 1) {
+        team_sync<64>();
+    } else {
+        epoch += NW;
+        __builtin_amdgcn_wave_barrier();                     // (lockstep on hardware; orders the emulator's lanes)
+        FRAD_LGKM0();                                        // this wave's LDS traffic is done
+        if ((threadIdx.x & 63) == 0) FRAD_LDS_ADD(ctr, 1u);
+        while (FRAD_LDS_LOAD(ctr) < epoch) FRAD_NAP();       // every arrival is a +1; never reset
+        FRAD_LGKM0();
+    }
+}
+
+template <typename T, int BITS, int SH, int CC>
+__device__ __forceinline__ u64 pack_frame_pairs(const unsigned char* data, unsigned char* __restrict__ dst, bool le, int utid, int M) {
+    constexpr int U = unit_values(BITS), UB = unit_bytes(BITS);
+    constexpr int V = U > 2 * CC ? U : 2 * CC, KB = V / CC;
+    const int tasks = (2 * M * CC) / V, uth = CC * 64;
+    u64 mx = 0;
+    for (int u = utid; u < tasks; u += uth) {
+        u64 codes[V];
+        const int s0 = (u * KB) >> 1;
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const cx<T>* buf = reinterpret_cast<const cx<T>*>(data) + (long long)c * M;
+#pragma unroll
+            for (int kk = 0; kk < KB / 2; ++kk) {
+                const cx<T> z = buf[phys<T, SH>(s0 + kk)];
+                const u64 a = abs_bits((double)z.x), b = abs_bits((double)z.y);
+                mx = a > mx ? a : mx; mx = b > mx ? b : mx;
+                codes[(2 * kk) * CC + c] = storage_code<T>(z.x, BITS);
+                codes[(2 * kk + 1) * CC + c] = storage_code<T>(z.y, BITS);
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < V / U; ++w) {
+            u64 unit[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) unit[i] = codes[w * U + i];
+            uint32_t out[UB / 4];
+            pack_unit<BITS>(unit, le, out);
+            store_words<UB / 4>(dst + ((long long)u * (V / U) + w) * UB, out);
+        }
+    }
+    return mx;
+}
+// out-of-line so that the six storage formats do not count against the transform's registers
+template <typename T, int SH, int CC>
+__device__ FRAD_NOINLINE void pack_frame_pairs_any(int data_off, unsigned char* __restrict__ dst, double* absmax_f, int bits,
+                                                   int le, int utid, int M) {
+    FRAD_DYN_SMEM(smem);
+    const unsigned char* data = smem + data_off;
+    u64 mx;
+    switch (bits) {
+        case 12: mx = pack_frame_pairs<T, 12, SH, CC>(data, dst, false, utid, M); break;
+        case 16: mx = pack_frame_pairs<T, 16, SH, CC>(data, dst, le != 0, utid, M); break;
+        case 24: mx = pack_frame_pairs<T, 24, SH, CC>(data, dst, le != 0, utid, M); break;
+        case 32: mx = pack_frame_pairs<T, 32, SH, CC>(data, dst, le != 0, utid, M); break;
+        case 48: mx = pack_frame_pairs<T, 48, SH, CC>(data, dst, le != 0, utid, M); break;
+        default: mx = pack_frame_pairs<T, 64, SH, CC>(data, dst, le != 0, utid, M); break;
+    }
+    mx = wave_max_u64(mx);
+    if (absmax_f != nullptr && (threadIdx.x & 63) == 0 && mx != 0) atomicMax(reinterpret_cast<u64*>(absmax_f), mx);
+}
+
+template <typename T, typename PL, int LG, int CC>
+__global__ void __launch_bounds__(512, 2)
+k_p0_fwd_unit(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload, double* absmax,
+              const cx<T>* __restrict__ blob, Geom g) {
+    constexpr int LOG2M = PL::LOG2M, M = 1 << LOG2M, N = 2 * M, TEAM = PL::TEAM, SH = PL::SH;
+    static_assert(TEAM == 64, "one wave per channel-frame");
+    constexpr int TB = pers_table_bytes<T, PL>(), CTRB = 64;
+    constexpr int CPT = (N << LG) / (16 * TEAM), EPC = 16 >> LG;
+    constexpr int UTH = CC * 64, UPB = 8 / CC;               // threads per unit, units per block
+    FRAD_DYN_SMEM(smem);
+    pers_load_tables<T, PL>(smem, blob);
+    unsigned* ctrs = reinterpret_cast<unsigned*>(smem + TB);
+    if (threadIdx.x < 16) ctrs[threadIdx.x] = 0;
+    const cx<T>* ltab = reinterpret_cast<const cx<T>*>(smem);
+    const cx<T>* lpost = ltab + PersLayout<PL>::OFFP;
+    const int unit = threadIdx.x / UTH, utid0 = threadIdx.x - unit * UTH;
+    const int data_off = TB + CTRB + unit * CC * M * (int)sizeof(cx<T>);
+    unsigned char* data = smem + data_off;                   // this unit's CC channel buffers
+    unsigned* ctr = ctrs + unit;
+    unsigned epoch = 0;
+    const int mode = g.in_mode;
+    const long long rowb = (long long)CC << LG, frameb = (g.frame_stride * CC) << LG;
+    constexpr int cpf = (N * CC << LG) / 16, slabs = (CC << LG) / 16 > 0 ? (CC << LG) / 16 : 1;
+    uint32_t pf[CPT][4];
+    int utid = utid0;
+
+    auto locate = [&](int i) -> int {                        // chunk (inside the frame) of prefetch slot i
+        if (mode == 3) {
+            const int task = utid + (i >> 2) * UTH, zq = task / slabs, sl = task - zq * slabs;
+            return (zq * 4 + (i & 3)) * slabs + sl;
+        } else if (mode == 2) {
+            return (utid + (i >> 1) * UTH) * 2 + (i & 1);
+        }
+        return utid + i * UTH;
+    };
+    auto prefetch = [&](long long f) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) load_words<4>(pcm + f * frameb + (long long)locate(i) * 16, pf[i]);
+    };
+    auto put = [&](int c, int zq, T e0, T e1, T e2, T e3) {
+        cx<T>* b = reinterpret_cast<cx<T>*>(data) + (long long)c * M;
+        b[phys<T, SH>(zq)] = cx<T>{e0, e2};
+        b[phys<T, SH>(M - 1 - zq)] = cx<T>{e3, e1};
+    };
+    auto stage_write_c = [&](auto code_tag, auto raw_tag) {
+        constexpr int CODE = decltype(code_tag)::value;
+        constexpr bool RAW = decltype(raw_tag)::value != 0;
+        if (mode == 3) {
+            if constexpr (CPT % 4 == 0) {
+#pragma unroll
+                for (int k = 0; k < CPT / 4; ++k) {
+                    const int task = utid + k * UTH, zq = task / slabs, sl = task - zq * slabs;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        T v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = cvt_pcm_c<T, CODE, RAW>(word_elem<LG>(pf[4 * k + i], e));
+                        put(sl * EPC + e, zq, v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+        } else if (mode == 2) {
+            if constexpr (CPT % 2 == 0 && (8 >> LG) == CC) {
+#pragma unroll
+                for (int k = 0; k < CPT / 2; ++k) {
+                    const int zq = utid + k * UTH;
+#pragma unroll
+                    for (int c = 0; c < CC; ++c) {
+                        T v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int idx = i * CC + c;
+                            v[i] = cvt_pcm_c<T, CODE, RAW>(word_elem<LG>(pf[2 * k + idx / EPC], idx % EPC));
+                        }
+                        put(c, zq, v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+        } else {
+            constexpr int GPC = (EPC / CC) / 4;
+            if constexpr (GPC >= 1) {
+#pragma unroll
+                for (int i = 0; i < CPT; ++i) {
+                    const int ch = utid + i * UTH;
+#pragma unroll
+                    for (int gi = 0; gi < GPC; ++gi)
+#pragma unroll
+                        for (int c = 0; c < CC; ++c) {
+                            T v[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = cvt_pcm_c<T, CODE, RAW>(word_elem<LG>(pf[i], (gi * 4 + r) * CC + c));
+                            put(c, ch * GPC + gi, v[0], v[1], v[2], v[3]);
+                        }
+                }
+            }
+        }
+    };
+
+    const long long stride = (long long)gridDim.x * UPB;
+    long long f = (long long)blockIdx.x * UPB + unit;
+    if (f < g.n_frames) prefetch(f);
+    __syncthreads();                                          // tables and counters are set up
+    while (f < g.n_frames) {
+        utid = utid0; FRAD_OPAQUE(utid);                      // no hoisting of per-lane addresses out of the loop
+        dispatch_pcm<LG>(g.dtype, g.raw_be, [&](auto c, auto r) { stage_write_c(c, r); });
+        unit_barrier<CC>(ctr, epoch);
+        const long long next = f + stride;
+        if (next < g.n_frames) prefetch(next);                // lands while this frame is transformed
+        int t = utid & 63, co = (utid >> 6) * M;
+        FRAD_OPAQUE(t); FRAD_OPAQUE(co);
+        cx<T>* buf = reinterpret_cast<cx<T>*>(data) + co;
+        fft_team_lt<T, PL, false>(buf, t, ltab);
+        dct_post<T, LOG2M, 1, TEAM, SH, true>(buf, t, lpost);
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) FRAD_OPAQUE(pf[i][j]);    // retire the prefetch before the store burst
+        unit_barrier<CC>(ctr, epoch);
+        pack_frame_pairs_any<T, SH, CC>(data_off, payload + f * g.payload_stride, absmax ? absmax + f : nullptr, g.bits, g.le, utid, M);
+        unit_barrier<CC>(ctr, epoch);
+        f = next;
+    }
+}
+
+template <int SH, int CC>
+__device__ FRAD_NOINLINE void store_frame_quads(int data_off, double* __restrict__ dstf, int utid, int M) {
+    FRAD_DYN_SMEM(smem);
+    const unsigned char* data = smem + data_off;
+    const int quads = M / 2, uth = CC * 64;                   // N / 4
+    for (int zq = utid; zq < quads; zq += uth) {
+        double row[4][CC];
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const cx<double>* buf = reinterpret_cast<const cx<double>*>(data) + (long long)c * M;
+            const cx<double> a = buf[phys<double, SH>(zq)], b = buf[phys<double, SH>(M - 1 - zq)];
+            row[0][c] = a.x; row[2][c] = a.y; row[3][c] = b.x; row[1][c] = b.y;
+        }
+        double2* dst = reinterpret_cast<double2*>(dstf + (long long)zq * 4 * CC);
+        if constexpr (CC == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { double2 v; v.x = row[i][0]; v.y = row[i][1]; dst[i] = v; }
+        } else {
+            double2 v0, v1; v0.x = row[0][0]; v0.y = row[1][0]; v1.x = row[2][0]; v1.y = row[3][0];
+            dst[0] = v0; dst[1] = v1;
+        }
+    }
+}
+
+template <typename PL, int BITS, int CC>
+__global__ void __launch_bounds__(512, 2)
+k_p0_inv_unit(const unsigned char* __restrict__ payload, double* __restrict__ out, const cx<double>* __restrict__ blob, Geom g) {
+    constexpr int LOG2M = PL::LOG2M, M = 1 << LOG2M, N = 2 * M, TEAM = PL::TEAM, SH = PL::SH;
+    static_assert(TEAM == 64, "one wave per channel-frame");
+    constexpr int TB = pers_table_bytes<double, PL>(), CTRB = 64;
+    constexpr int U = unit_values(BITS), UB = unit_bytes(BITS);
+    constexpr int V = U > 2 * CC ? U : 2 * CC, KB = V / CC, UPV = V / U;
+    constexpr int TPT = N / (V * TEAM);
+    static_assert(TPT >= 1 && TPT * V * TEAM == N, "tasks per thread");
+    constexpr int UTH = CC * 64, UPB = 8 / CC;
+    FRAD_DYN_SMEM(smem);
+    pers_load_tables<double, PL>(smem, blob);
+    unsigned* ctrs = reinterpret_cast<unsigned*>(smem + TB);
+    if (threadIdx.x < 16) ctrs[threadIdx.x] = 0;
+    const cx<double>* ltab = reinterpret_cast<const cx<double>*>(smem);
+    const cx<double>* lpost = ltab + PersLayout<PL>::OFFP;
+    const int unit = threadIdx.x / UTH, utid0 = threadIdx.x - unit * UTH;
+    const int data_off = TB + CTRB + unit * CC * M * 16;
+    unsigned char* data = smem + data_off;
+    unsigned* ctr = ctrs + unit;
+    unsigned epoch = 0;
+    const bool le = g.le && (BITS % 8 == 0);
+    uint32_t pf[TPT][UPV][UB / 4];
+    int utid = utid0;
+
+    auto prefetch = [&](long long f) {
+        const unsigned char* src = payload + f * g.payload_stride;
+#pragma unroll
+        for (int i = 0; i < TPT; ++i)
+#pragma unroll
+            for (int w = 0; w < UPV; ++w) load_words<UB / 4>(src + ((long long)(utid + i * UTH) * UPV + w) * UB, pf[i][w]);
+    };
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int i = 0; i < TPT; ++i) {
+            const int u = utid + i * UTH;
+            u64 codes[V];
+#pragma unroll
+            for (int w = 0; w < UPV; ++w) {
+                u64 un[U];
+                unpack_unit<BITS>(pf[i][w], le, un);
+#pragma unroll
+                for (int e = 0; e < U; ++e) codes[w * U + e] = un[e];
+            }
+            const int s0 = (u * KB) >> 1;
+#pragma unroll
+            for (int c = 0; c < CC; ++c) {
+                cx<double>* b = reinterpret_cast<cx<double>*>(data) + (long long)c * M;
+#pragma unroll
+                for (int kk = 0; kk < KB / 2; ++kk)
+                    b[phys<double, SH>(s0 + kk)] = cx<double>{code_to_f64(codes[(2 * kk) * CC + c], BITS),
+                                                              code_to_f64(codes[(2 * kk + 1) * CC + c], BITS)};
+            }
+        }
+    };
+
+    const long long stride = (long long)gridDim.x * UPB;
+    long long f = (long long)blockIdx.x * UPB + unit;
+    if (f < g.n_frames) prefetch(f);
+    __syncthreads();
+    while (f < g.n_frames) {
+        utid = utid0; FRAD_OPAQUE(utid);
+        stage_write();
+        unit_barrier<CC>(ctr, epoch);
+        const long long next = f + stride;
+        if (next < g.n_frames) prefetch(next);
+        int t = utid & 63, co = (utid >> 6) * M;
+        FRAD_OPAQUE(t); FRAD_OPAQUE(co);
+        cx<double>* buf = reinterpret_cast<cx<double>*>(data) + co;
+        dct_pre_inverse<double, LOG2M, 1, TEAM, SH, true>(buf, t, lpost);
+        fft_team_lt<double, PL, true>(buf, t, ltab);
+#pragma unroll
+        for (int i = 0; i < TPT; ++i)
+#pragma unroll
+            for (int w = 0; w < UPV; ++w)
+#pragma unroll
+                for (int j = 0; j < UB / 4; ++j) FRAD_OPAQUE(pf[i][w][j]);
+        unit_barrier<CC>(ctr, epoch);
+        store_frame_quads<SH, CC>(data_off, out + f * (long long)N * CC, utid, M);
+        unit_barrier<CC>(ctr, epoch);
+        f = next;
     }
 }
 

@@ -3,10 +3,12 @@
 // Lets the build container (no GPU) execute frad_kernels.hpp / frad_hip.hip unchanged, compiled by
 // g++ with -DFRAD_HOST_EMULATION, so that indexing, packing and barrier structure can be checked
 // against the oracle and under AddressSanitizer.  One std::thread per HIP thread, one block at a
-// time; every barrier flavour (block barrier, wave barrier, shuffles) is a std::barrier over the
-// block, which is a superset of the hardware semantics as long as the kernels call them uniformly
-// -- which the real hardware requires of __syncthreads anyway.  Never linked into libfrad_hip.so.
+// time; __syncthreads is a std::barrier over the block, wave barriers and shuffles a std::barrier
+// over the 64 lanes of the wave (lanes are NOT in lockstep here, so every wave-level exchange in
+// the kernels must be fenced -- which the emulator therefore also checks).  Never linked into
+// libfrad_hip.so.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <barrier>
 #include <cmath>
@@ -31,10 +33,13 @@ struct alignas(16) double2 { double x, y; };
 
 namespace emu {
 struct Block {
-    std::barrier<> bar;
+    std::barrier<> bar;                                       // block-wide (__syncthreads)
+    std::vector<std::unique_ptr<std::barrier<>>> wave;        // one per 64-lane wave (wave-level ops)
     std::vector<unsigned long long> scratch;
     std::vector<unsigned char> smem;
-    explicit Block(unsigned n, size_t lds) : bar(n), scratch(n), smem(lds + 64) {}
+    explicit Block(unsigned n, size_t lds) : bar(n), scratch(n), smem(lds + 64) {
+        for (unsigned w = 0; w * 64 < n; ++w) wave.emplace_back(new std::barrier<>(std::min(64u, n - w * 64)));
+    }
 };
 inline thread_local Block* blk = nullptr;
 inline thread_local dim3 t_idx, b_idx, b_dim, g_dim;
@@ -68,15 +73,16 @@ template <typename F> void launch(dim3 grid, dim3 block, size_t lds, F&& body) {
 inline void __syncthreads() { emu::blk->bar.arrive_and_wait(); }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
-inline void __builtin_amdgcn_wave_barrier() { emu::blk->bar.arrive_and_wait(); }
+inline void __builtin_amdgcn_wave_barrier() { emu::blk->wave[emu::t_idx.x / 64]->arrive_and_wait(); }
 
 inline unsigned long long __shfl_xor(unsigned long long v, int mask, int /*width*/) {
     auto* b = emu::blk;
+    auto& wb = *b->wave[emu::t_idx.x / 64];
     b->scratch[emu::t_idx.x] = v;
-    b->bar.arrive_and_wait();
-    const unsigned src = emu::t_idx.x ^ (unsigned)mask;
+    wb.arrive_and_wait();
+    const unsigned src = emu::t_idx.x ^ (unsigned)mask;                     // stays inside the wave (mask < 64)
     const unsigned long long r = src < emu::b_dim.x ? b->scratch[src] : v;
-    b->bar.arrive_and_wait();
+    wb.arrive_and_wait();
     return r;
 }
 inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) {
