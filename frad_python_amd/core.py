@@ -129,3 +129,68 @@ def digital_batch(profile: int, payload: torch.Tensor, n_frames: int, N: int, C:
     with torch.cuda.device(payload.device):
         fn(payload.data_ptr(), payload_stride, n_frames, N, C, bits, flags, out.data_ptr(), _stream_ptr())
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# profile 1 (psychoacoustic quantiser): the integer arrays either side of the host entropy coder
+# ---------------------------------------------------------------------------------------------
+P1_DEPTHS = (8, 12, 16, 24, 32, 48, 64)                # ref: fourier/profile1.py:7
+P1_BANDS = 27
+
+
+def p1_analogue_batch(pcm: torch.Tensor, pcm_format: str, n_frames: int, N: int, C: int, bits: int, srate: int,
+                      loss_level: float, *, frame_stride: int | None = None, n_valid: int | None = None,
+                      raw_be_ints: bool = True) -> tuple[torch.Tensor, torch.Tensor]:
+    """``profile1.analogue`` up to the Exp-Golomb coder (profile1.py:15-40), batched.
+
+    Frame i reads ``n_valid`` (default N) sample-frames at ``pcm + i*frame_stride`` (the hop when the
+    encoder overlaps) and is zero-padded to the compact frame size N.  Returns ``q`` int32
+    [n_frames, N, C] and ``tq`` int32 [n_frames, 27, C]."""
+    _require_cuda(pcm, "pcm")
+    lib = _lib.load()
+    code = pcm_dtype_code(pcm_format)
+    hop = N if frame_stride is None else frame_stride
+    nv = N if n_valid is None else n_valid
+    need = ((n_frames - 1) * hop + nv) * C * itemsize_of(code) if n_frames else 0
+    if pcm.numel() * pcm.element_size() < need:
+        raise ValueError(f"pcm holds {pcm.numel() * pcm.element_size()} bytes, {need} needed")
+    q = torch.empty((n_frames, N, C), dtype=torch.int32, device=pcm.device)
+    tq = torch.empty((n_frames, P1_BANDS, C), dtype=torch.int32, device=pcm.device)
+    flags = int(raw_be_ints) * _lib.FRAD_RAW_BE_INTS
+    with torch.cuda.device(pcm.device):
+        lib.p1_analogue(pcm.data_ptr(), code, n_frames, N, C, hop, nv, bits, srate, float(loss_level), flags,
+                        q.data_ptr(), tq.data_ptr(), _stream_ptr())
+    return q, tq
+
+
+def p1_digital_batch(q: torch.Tensor, tq: torch.Tensor, N: int, C: int, bits: int, srate: int) -> torch.Tensor:
+    """``profile1.digital`` from the decoded integers on (profile1.py:65-77): float64 [n_frames, N, C]."""
+    _require_cuda(q, "q"); _require_cuda(tq, "tq")
+    if q.dtype != torch.int32 or tq.dtype != torch.int32:
+        raise TypeError("q and tq must be int32")
+    n_frames = q.shape[0]
+    out = torch.empty((n_frames, N, C), dtype=torch.float64, device=q.device)
+    with torch.cuda.device(q.device):
+        _lib.load().p1_digital(q.data_ptr(), tq.data_ptr(), n_frames, N, C, bits, srate, out.data_ptr(), _stream_ptr())
+    return out
+
+
+def p1_overlap_add(frames: torch.Tensor, overlap_ratio: int, prev_tail: torch.Tensor | None = None):
+    """The decoder's Hann cross-fade over consecutive decoded frames (decoder.py:28-46).
+
+    ``frames`` float64 [n_frames, N, C]; returns ``(out [n_frames, cut, C], next_tail [N - cut, C])``
+    with cut = N*(ratio-1)//ratio; ``prev_tail`` is the previous batch's ``next_tail`` (or None)."""
+    _require_cuda(frames, "frames")
+    n_frames, N, C = frames.shape
+    cut = N * (overlap_ratio - 1) // overlap_ratio
+    out = torch.empty((n_frames, cut, C), dtype=torch.float64, device=frames.device)
+    nxt = torch.empty((N - cut, C), dtype=torch.float64, device=frames.device)
+    if prev_tail is not None:
+        _require_cuda(prev_tail, "prev_tail")
+        if tuple(prev_tail.shape) != (N - cut, C):
+            raise ValueError("prev_tail must be [N - cut, C]")
+    with torch.cuda.device(frames.device):
+        _lib.load().p1_overlap_add(frames.data_ptr(), n_frames, N, C, overlap_ratio,
+                                   prev_tail.data_ptr() if prev_tail is not None else 0, out.data_ptr(), nxt.data_ptr(),
+                                   _stream_ptr())
+    return out, nxt

@@ -49,7 +49,6 @@ void unit_neg(long long p, long long q, long double& re, long double& im) {
     re = C; im = -S;
 }
 
-struct DirectTable { double* ct = nullptr; };
 
 std::mutex g_mu;
 std::map<std::tuple<int, int, int>, Tables> g_tables;        // (device, log2M, f32)
@@ -84,6 +83,8 @@ int build_tables(int log2m, Tables& out) {
     return FRAD_OK;
 }
 
+}  // namespace
+namespace frad {
 int get_tables(int log2m, bool f32, Tables& out) {
     int dev = 0; HIPCHK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_mu);
@@ -154,6 +155,9 @@ FastCfg fast_cfg(int N, int C, bool f32) {
     if (const char* e = getenv("FRAD_TUNE_LDS_PAD")) c.lds += (size_t)atoi(e);
     return c;
 }
+
+}  // namespace frad
+namespace {
 
 int check_common(const void* a, const void* b, long long n_frames, int N, int C, int bits) {
     if (n_frames < 0 || N < 1 || C < 1 || C > 256 || !valid_bits(bits)) return FRAD_E_INVALID;

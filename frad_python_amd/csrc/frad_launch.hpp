@@ -16,6 +16,13 @@ struct FastCfg {
     size_t lds = 0;
 };
 
+struct DirectTable { double* ct = nullptr; };        // cos(pi j / 2N), j in [0, 4N)
+
+// table caches and launch geometry (frad_hip.hip), shared with the profile-1 translation unit
+int get_tables(int log2m, bool f32, Tables& out);
+int get_direct(int N, DirectTable& out);
+FastCfg fast_cfg(int N, int C, bool f32);
+
 template <typename K> inline void allow_lds(K kernel, size_t bytes) {
     if (bytes > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);

@@ -1,10 +1,201 @@
-// profile 1 (psychoacoustic quantiser) entry points -- kernels K7/K8.
+// profile 1 (psychoacoustic quantiser) entry points -- kernels K7 / K8 (frad_p1.hpp).
+#include "frad_p1.hpp"
 #include "frad_launch.hpp"
 #include "../../include/frad_hip.h"
 
-extern "C" {
-int frad_p1_analogue(const void*, int32_t, int64_t, int32_t, int32_t, int64_t, int32_t, int32_t, int32_t, double,
-                     uint32_t, int32_t*, int32_t*, void*) { return FRAD_E_UNSUPPORTED; }
-int frad_p1_digital(const int32_t*, const int32_t*, int64_t, int32_t, int32_t, int32_t, int32_t, double*, void*) { return FRAD_E_UNSUPPORTED; }
-int frad_p1_overlap_add(const double*, int64_t, int32_t, int32_t, int32_t, const double*, double*, double*, void*) { return FRAD_E_UNSUPPORTED; }
+#include <climits>
+#include <cmath>
+
+using namespace frad;
+
+namespace {
+
+// ref: fourier/tools/p1tools.py:4-9 (Hz), fourier/profiles.py:5 (rates), :14-23 (frame sizes)
+const long long kEdgesHz[P1_BANDS + 1] = {0, 200, 400, 600, 800, 1000, 1200, 1400, 1600, 2000, 2400, 2800, 3200, 4000, 4800, 5600,
+                                          6800, 8000, 9600, 12000, 15600, 20000, 24000, 28800, 34400, 40800, 48000, 4294967295LL};
+const int kSrates[12] = {96000, 88200, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000};
+
+bool legal_compact_size(int n) {
+    for (int s = 0; s < 8; ++s)
+        for (int m : {128, 160, 192, 224}) if (n == (m << s)) return true;
+    return false;
 }
+int valid_srate(int srate) {                     // smallest table rate >= srate (profiles.py:7-8)
+    int best = -1;
+    for (int r : kSrates) if (r >= srate && (best < 0 || r < best)) best = r;
+    return best;
+}
+int p1_scale_bits(int bits) {                    // profile1.py:16: unknown depth -> 16
+    for (int b : {8, 12, 16, 24, 32, 48, 64}) if (b == bits) return bits;
+    return 16;
+}
+
+int make_tables(int N, int srate, int bits, double loss_level, P1Tables& tb) {
+    const int sr = valid_srate(srate);
+    if (sr < 0) return FRAD_E_INVALID;
+    for (int i = 0; i <= P1_BANDS; ++i) {        // Python round(): half-to-even == nearbyint in the default mode
+        const double e = nearbyint((double)N / ((double)sr / 2) * (double)kEdgesHz[i]);
+        tb.edge[i] = e > (double)INT_MAX ? INT_MAX : (int)e;
+    }
+    tb.nb_used = P1_BANDS;
+    for (int i = 0; i < P1_BANDS; ++i) {
+        const int a = tb.edge[i] < N ? tb.edge[i] : N, e = tb.edge[i + 1] < N ? tb.edge[i + 1] : N;
+        if (e <= a && tb.nb_used == P1_BANDS) tb.nb_used = i;        // the reference loop breaks at the first empty band
+        const double f = (double)(kEdgesHz[i] + kEdgesHz[i + 1]) / 2;
+        const double khz = f / 1000.0;
+        const double ath = pow(10.0, (3.64 * pow(khz, -0.8) - 6.5 * exp(-0.6 * pow(khz - 3.3, 2.0)) + 1e-3 * pow(khz, 4.0)) / 20);
+        tb.floor_[i] = ath < 1.0 ? ath : 1.0;
+    }
+    tb.scale = ldexp(1.0, p1_scale_bits(bits) - 1);
+    tb.loss = fabs(loss_level) > 0.125 ? fabs(loss_level) : 0.125;
+    return FRAD_OK;
+}
+
+thread_local int g_last = 0;
+#define P1CHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_last = (int)e_; return FRAD_E_HIP; } } while (0)
+
+template <int LOG2M>
+void go_fwd(int lg, const FastCfg& c, size_t lds, dim3 grid, hipStream_t s, const unsigned char* pcm, int32_t* q, int32_t* tq,
+            const Tables& t, const Geom& g, const P1Tables& tb, int ai) {
+    const cx<double>* tw = static_cast<const cx<double>*>(t.tw); const cx<double>* post = static_cast<const cx<double>*>(t.post);
+#define GO(LGV, MAXT) do { allow_lds(k_p1_fwd<LOG2M, LGV, MAXT>, lds); \
+        hipLaunchKernelGGL((k_p1_fwd<LOG2M, LGV, MAXT>), grid, dim3(c.threads), lds, s, pcm, q, tq, tw, post, g, tb, ai); } while (0)
+#define GOL(LGV) do { if (c.threads <= 256) GO(LGV, 256); else GO(LGV, 1024); } while (0)
+    switch (lg) { case 0: GOL(0); break; case 1: GOL(1); break; case 2: GOL(2); break; default: GOL(3); break; }
+#undef GOL
+#undef GO
+}
+template <int LOG2M>
+void go_inv(const FastCfg& c, size_t lds, dim3 grid, hipStream_t s, const int32_t* q, const int32_t* tq, double* out,
+            const Tables& t, const Geom& g, const P1Tables& tb) {
+    const cx<double>* tw = static_cast<const cx<double>*>(t.tw); const cx<double>* post = static_cast<const cx<double>*>(t.post);
+    if (c.threads <= 256) { allow_lds(k_p1_inv<LOG2M, 256>, lds); hipLaunchKernelGGL((k_p1_inv<LOG2M, 256>), grid, dim3(c.threads), lds, s, q, tq, out, tw, post, g, tb); }
+    else { allow_lds(k_p1_inv<LOG2M, 1024>, lds); hipLaunchKernelGGL((k_p1_inv<LOG2M, 1024>), grid, dim3(c.threads), lds, s, q, tq, out, tw, post, g, tb); }
+}
+
+Geom p1_geom(long long n_frames, int N, int C, long long stride, int n_valid, int dtype, uint32_t flags) {
+    Geom g{};
+    g.n_frames = n_frames; g.frame_stride = stride; g.payload_stride = 0; g.N = N; g.C = C; g.bits = 32; g.le = 0;
+    g.dtype = dtype; g.raw_be = (flags & FRAD_RAW_BE_INTS) ? 1 : 0; g.fpb = 1; g.n_valid = n_valid; g.cg = C; g.in_mode = 0; g.cc_fast = 0;
+    return g;
+}
+constexpr size_t kLds = 160 * 1024;
+
+}  // namespace
+
+extern "C" {
+
+int frad_p1_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C, int64_t frame_stride,
+                     int32_t n_valid, int32_t bits, int32_t srate, double loss_level, uint32_t flags,
+                     int32_t* q, int32_t* tq, void* stream) {
+    if (n_frames < 0 || C < 1 || C > 64 || !legal_compact_size(N) || n_valid < 0 || n_valid > N) return FRAD_E_INVALID;
+    if (pcm_dtype < 0 || pcm_dtype > 23) return FRAD_E_INVALID;
+    if (n_frames == 0) return FRAD_OK;
+    if (!pcm || !q || !tq) return FRAD_E_INVALID;
+    const int kind = pcm_dtype >> 3, lg = (pcm_dtype >> 1) & 3;
+    if (kind == 2 && lg <= 2) return FRAD_E_UNSUPPORTED;          // f32 / f16 PCM: the reference's mixed-precision path
+    P1Tables tb;
+    int rc = make_tables(N, srate, bits, loss_level, tb);
+    if (rc != FRAD_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Geom g = p1_geom(n_frames, N, C, frame_stride, n_valid, pcm_dtype, flags);
+    const int ai = ((reinterpret_cast<uintptr_t>(pcm) & 15u) == 0 && (((frame_stride * C) << lg) % 16 == 0) &&
+                    ((((long long)N * C) << lg) % 16 == 0)) ? 1 : 0;
+    const unsigned char* in = static_cast<const unsigned char*>(pcm);
+    FastCfg c = fast_cfg(N, C, false);
+    if (c.ok && c.cg == C) {
+        const int M = 1 << c.log2m;
+        while (c.fpb > 1 && (size_t)c.fpb * C * (M * 16 + P1_BANDS * 8) > 80 * 1024) { c.fpb -= 1; }
+        c.threads = c.fpb * C * c.team;
+        if (c.threads > 1024 || c.threads % 64) return FRAD_E_UNSUPPORTED;
+        const size_t lds = (size_t)c.fpb * C * (M * 16 + P1_BANDS * 8);
+        if (lds > kLds) return FRAD_E_UNSUPPORTED;
+        Tables t; rc = get_tables(c.log2m, false, t);
+        if (rc != FRAD_OK) return rc;
+        g.fpb = c.fpb;
+        dim3 grid((unsigned)((n_frames + c.fpb - 1) / c.fpb));
+        switch (c.log2m) {
+            case 6: go_fwd<6>(lg, c, lds, grid, s, in, q, tq, t, g, tb, ai); break;
+            case 7: go_fwd<7>(lg, c, lds, grid, s, in, q, tq, t, g, tb, ai); break;
+            case 8: go_fwd<8>(lg, c, lds, grid, s, in, q, tq, t, g, tb, ai); break;
+            case 9: go_fwd<9>(lg, c, lds, grid, s, in, q, tq, t, g, tb, ai); break;
+            case 10: go_fwd<10>(lg, c, lds, grid, s, in, q, tq, t, g, tb, ai); break;
+            case 11: go_fwd<11>(lg, c, lds, grid, s, in, q, tq, t, g, tb, ai); break;
+            case 12: go_fwd<12>(lg, c, lds, grid, s, in, q, tq, t, g, tb, ai); break;
+            default: go_fwd<13>(lg, c, lds, grid, s, in, q, tq, t, g, tb, ai); break;
+        }
+    } else {
+        const size_t lds = 2 * (size_t)N * C * 8 + (size_t)P1_BANDS * C * 8;
+        if (lds > kLds || n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
+        DirectTable d; rc = get_direct(N, d);
+        if (rc != FRAD_OK) return rc;
+        dim3 grid((unsigned)n_frames);
+#define GOD(LGV) do { allow_lds(k_p1_fwd_direct<LGV>, lds); hipLaunchKernelGGL((k_p1_fwd_direct<LGV>), grid, dim3(256), lds, s, in, q, tq, d.ct, g, tb, ai); } while (0)
+        switch (lg) { case 0: GOD(0); break; case 1: GOD(1); break; case 2: GOD(2); break; default: GOD(3); break; }
+#undef GOD
+    }
+    P1CHK(hipGetLastError());
+    return FRAD_OK;
+}
+
+int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32_t N, int32_t C, int32_t bits, int32_t srate,
+                    double* pcm_out, void* stream) {
+    if (n_frames < 0 || C < 1 || C > 64 || !legal_compact_size(N)) return FRAD_E_INVALID;
+    if (n_frames == 0) return FRAD_OK;
+    if (!q || !tq || !pcm_out) return FRAD_E_INVALID;
+    P1Tables tb;
+    int rc = make_tables(N, srate, bits, 1.0, tb);
+    if (rc != FRAD_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Geom g = p1_geom(n_frames, N, C, N, N, FRAD_PCM_F64LE, 0);
+    FastCfg c = fast_cfg(N, C, false);
+    if (c.ok && c.cg == C) {
+        const int M = 1 << c.log2m;
+        while (c.fpb > 1 && (size_t)c.fpb * C * (M * 16 + P1_BANDS * 8) > 80 * 1024) { c.fpb -= 1; }
+        c.threads = c.fpb * C * c.team;
+        if (c.threads > 1024 || c.threads % 64) return FRAD_E_UNSUPPORTED;
+        const size_t lds = (size_t)c.fpb * C * (M * 16 + P1_BANDS * 8);
+        if (lds > kLds) return FRAD_E_UNSUPPORTED;
+        Tables t; rc = get_tables(c.log2m, false, t);
+        if (rc != FRAD_OK) return rc;
+        g.fpb = c.fpb;
+        dim3 grid((unsigned)((n_frames + c.fpb - 1) / c.fpb));
+        switch (c.log2m) {
+            case 6: go_inv<6>(c, lds, grid, s, q, tq, pcm_out, t, g, tb); break;
+            case 7: go_inv<7>(c, lds, grid, s, q, tq, pcm_out, t, g, tb); break;
+            case 8: go_inv<8>(c, lds, grid, s, q, tq, pcm_out, t, g, tb); break;
+            case 9: go_inv<9>(c, lds, grid, s, q, tq, pcm_out, t, g, tb); break;
+            case 10: go_inv<10>(c, lds, grid, s, q, tq, pcm_out, t, g, tb); break;
+            case 11: go_inv<11>(c, lds, grid, s, q, tq, pcm_out, t, g, tb); break;
+            case 12: go_inv<12>(c, lds, grid, s, q, tq, pcm_out, t, g, tb); break;
+            default: go_inv<13>(c, lds, grid, s, q, tq, pcm_out, t, g, tb); break;
+        }
+    } else {
+        const size_t lds = 2 * (size_t)N * C * 8 + (size_t)P1_BANDS * C * 8;
+        if (lds > kLds || n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
+        DirectTable d; rc = get_direct(N, d);
+        if (rc != FRAD_OK) return rc;
+        allow_lds(k_p1_inv_direct<0>, lds);
+        hipLaunchKernelGGL(k_p1_inv_direct<0>, dim3((unsigned)n_frames), dim3(256), lds, s, q, tq, pcm_out, d.ct, g, tb);
+    }
+    P1CHK(hipGetLastError());
+    return FRAD_OK;
+}
+
+int frad_p1_overlap_add(const double* frames, int64_t n_frames, int32_t N, int32_t C, int32_t overlap_ratio,
+                        const double* prev_tail, double* ola_out, double* next_tail, void* stream) {
+    if (n_frames < 0 || N < 1 || C < 1 || overlap_ratio < 2 || overlap_ratio > 256) return FRAD_E_INVALID;
+    if (n_frames == 0) return FRAD_OK;
+    if (!frames || !ola_out) return FRAD_E_INVALID;
+    const int cut = (int)((long long)N * (overlap_ratio - 1) / overlap_ratio);     // decoder.py:44
+    const long long total = n_frames * (long long)cut * C;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_p1_ola<0>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), frames, (long long)n_frames, N, C,
+                       cut, prev_tail, ola_out, next_tail);
+    P1CHK(hipGetLastError());
+    return FRAD_OK;
+}
+
+}  // extern "C"

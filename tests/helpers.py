@@ -63,6 +63,32 @@ class EmuBackend:
         return out[:F]
 
 
+    # ---- profile 1 ----
+    def p1_analogue(self, raw, fmt, F, N, C, bits, srate, loss, frame_stride=None, n_valid=None):
+        from frad_python_amd.backend.pcmformat import pcm_dtype_code
+        src = np.zeros(raw.nbytes + 64, np.uint8); src[:raw.nbytes] = raw.view(np.uint8).reshape(-1)
+        q = np.zeros((max(F, 1), N, C), np.int32); tq = np.zeros((max(F, 1), 27, C), np.int32)
+        self.lib.p1_analogue(src.ctypes.data, pcm_dtype_code(fmt), F, N, C, N if frame_stride is None else frame_stride,
+                             N if n_valid is None else n_valid, bits, srate, loss, 2, q.ctypes.data, tq.ctypes.data)
+        return q[:F], tq[:F]
+
+    def p1_digital(self, q, tq, N, C, bits, srate):
+        F = q.shape[0]
+        out = np.zeros((max(F, 1), N, C))
+        qq, tt = np.ascontiguousarray(q, np.int32), np.ascontiguousarray(tq, np.int32)
+        self.lib.p1_digital(qq.ctypes.data, tt.ctypes.data, F, N, C, bits, srate, out.ctypes.data)
+        return out[:F]
+
+    def p1_ola(self, frames, ratio, prev_tail=None):
+        F, N, C = frames.shape
+        cut = N * (ratio - 1) // ratio
+        fr = np.ascontiguousarray(frames)
+        out = np.zeros((F, cut, C)); nxt = np.zeros((N - cut, C))
+        pt = np.ascontiguousarray(prev_tail) if prev_tail is not None else None
+        self.lib.p1_overlap_add(fr.ctypes.data, F, N, C, ratio, pt.ctypes.data if pt is not None else 0, out.ctypes.data, nxt.ctypes.data)
+        return out, nxt
+
+
 class GpuBackend:
     name = "gpu"
 
@@ -100,6 +126,32 @@ class GpuBackend:
         out = core.digital_batch(profile, view, F, N, C, bits, le, payload_stride=stride)
         t.cuda.synchronize()
         return out.cpu().numpy()
+
+    # ---- profile 1 ----
+    def p1_analogue(self, raw, fmt, F, N, C, bits, srate, loss, frame_stride=None, n_valid=None):
+        from frad_python_amd import core
+        t = self.torch
+        src = t.zeros(raw.nbytes + 64, dtype=t.uint8, device=self.dev)
+        src[:raw.nbytes] = t.from_numpy(raw.view(np.uint8).reshape(-1).copy()).to(self.dev)
+        q, tq = core.p1_analogue_batch(src, fmt, F, N, C, bits, srate, loss, frame_stride=frame_stride, n_valid=n_valid)
+        t.cuda.synchronize()
+        return q.cpu().numpy(), tq.cpu().numpy()
+
+    def p1_digital(self, q, tq, N, C, bits, srate):
+        from frad_python_amd import core
+        t = self.torch
+        out = core.p1_digital_batch(t.from_numpy(np.ascontiguousarray(q, np.int32)).to(self.dev),
+                                    t.from_numpy(np.ascontiguousarray(tq, np.int32)).to(self.dev), N, C, bits, srate)
+        t.cuda.synchronize()
+        return out.cpu().numpy()
+
+    def p1_ola(self, frames, ratio, prev_tail=None):
+        from frad_python_amd import core
+        t = self.torch
+        pt = t.from_numpy(np.ascontiguousarray(prev_tail)).to(self.dev) if prev_tail is not None else None
+        out, nxt = core.p1_overlap_add(t.from_numpy(np.ascontiguousarray(frames)).to(self.dev), ratio, pt)
+        t.cuda.synchronize()
+        return out.cpu().numpy(), nxt.cpu().numpy()
 
 
 def oracle_frames(fo, profile, raw, fmt, F, N, C, bits, le, frame_stride=None, raw_be=True):

@@ -1,0 +1,107 @@
+"""Profile 1 (lossy, psychoacoustic quantiser) parity: kernels K7 / K8 and the overlap-add.
+
+Contract: the pre-entropy integers are compared with the oracle / the
+reference-generated fixture G4 value by value.  pow / log on the GPU and in numpy may round a
+half-way case differently, so the assertion is: |dq| <= 1 everywhere and the fraction of differing
+values <= 1e-3 (measured rates are printed); decoded PCM is compared by absolute error and PSNR.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_npz
+from helpers import EmuBackend, GpuBackend
+from frad_python_amd import synth
+from oracle import frad_oracle as fo
+
+_backends = {}
+
+
+@pytest.fixture(params=[pytest.param("emu"), pytest.param("gpu", marks=pytest.mark.gpu)])
+def be(request):
+    if request.param not in _backends:
+        _backends[request.param] = EmuBackend() if request.param == "emu" else GpuBackend()
+    return _backends[request.param]
+
+
+def _check_ints(got, want, what):
+    d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+    assert d.max() <= 1, f"{what}: max |diff| {d.max()}"
+    frac = np.count_nonzero(d) / d.size
+    assert frac <= 1e-3, f"{what}: {frac:.2e} of the values differ"
+    return frac
+
+
+def test_p1_golden_g4_quantiser_and_decode(be, g4):
+    frames = g4["frames_s16le"]                                # 3 overlapped frames, hop 1920, N = 2048, C = 2
+    raw = np.ascontiguousarray(frames)
+    for lv in (0, 10, 20):
+        ll = 1.25 ** lv / 19.0 + 0.5
+        q, tq = be.p1_analogue(raw, "s16le", 3, 2048, 2, 16, 48000, ll)
+        for i in range(3):
+            wq = np.zeros(4096, np.int32); w = g4[f"lv{lv}_f{i}_q"]; wq[:w.size] = w      # the Golomb decoder drops trailing zeros
+            wt = np.zeros(54, np.int32); w = g4[f"lv{lv}_f{i}_tq"]; wt[:w.size] = w
+            _check_ints(q[i].reshape(-1), wq, f"q lv{lv} f{i}")
+            _check_ints(tq[i].reshape(-1), wt, f"tq lv{lv} f{i}")
+            dec = be.p1_digital(wq.reshape(1, 2048, 2), wt.reshape(1, 27, 2), 2048, 2, 16, 48000)[0]
+            ref = g4[f"lv{lv}_f{i}_dec"]
+            assert np.max(np.abs(dec - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("geom", [(2048, 2, 48000, 5), (512, 1, 44100, 3), (2048, 1, 96000, 2), (1024, 2, 8000, 2),
+                                  (640, 1, 32000, 2), (128, 2, 48000, 4), (4096, 2, 48000, 1), (2560, 2, 48000, 1)])
+def test_p1_vs_oracle_sizes_and_rates(be, geom):
+    N, C, srate, F = geom
+    if be.name == "emu" and N > 2048:
+        pytest.skip("emulator: covered by the smaller sizes")
+    x = synth.harmonic_mix(F * N, C, srate, seed=N + C)
+    raw = synth.to_pcm(x, "s16le")
+    dt = fo.pcm_dtype("s16le")
+    for loss in (0.553, 5.065):
+        q, tq = be.p1_analogue(raw, "s16le", F, N, C, 16, srate, loss)
+        for f in range(F):
+            wq, wt, aux = fo.p1_analogue_pre(fo.to_f64(raw[f * N:(f + 1) * N], dt), 16, srate, loss)
+            _check_ints(q[f].reshape(-1), wq, f"q N={N} f{f}")
+            _check_ints(tq[f].reshape(-1), wt, f"tq N={N} f{f}")
+            dec = be.p1_digital(wq.reshape(1, N, C).astype(np.int32), wt.reshape(1, 27, C).astype(np.int32), N, C, 16, srate)[0]
+            ref = fo.p1_digital_post(wq, wt, 2, C, srate, N)
+            assert np.max(np.abs(dec - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+
+
+def test_p1_short_frame_is_zero_padded(be):
+    """flush: the last frame is shorter than the compact size and is padded (profile1.py:19)."""
+    N, C, nv = 1024, 2, 900
+    raw = synth.to_pcm(synth.harmonic_mix(nv, C, 48000, seed=9), "s16le")
+    q, tq = be.p1_analogue(raw, "s16le", 1, N, C, 16, 48000, 1.0, n_valid=nv)
+    wq, wt, aux = fo.p1_analogue_pre(fo.to_f64(raw, fo.pcm_dtype("s16le")), 16, 48000, 1.0)
+    assert aux["dlen"] == N
+    _check_ints(q[0].reshape(-1), wq, "q"); _check_ints(tq[0].reshape(-1), wt, "tq")
+
+
+def test_p1_overlapped_gather_and_overlap_add(be, g4):
+    """Encoder overlap = strided frame gather; decoder overlap = Hann cross-fade (R2, R8)."""
+    arr = load_npz("g3_p1_streams.npz")
+    sig = arr["p1_input_s16le"]                                # 3*1920 + 700 sample-frames, stereo
+    q, tq = be.p1_analogue(np.ascontiguousarray(sig), "s16le", 3, 2048, 2, 16, 48000, 0.5 + 1.25 ** 20 / 19.0, frame_stride=1920)
+    for i in range(3):
+        w = g4[f"lv20_f{i}_q"]; wq = np.zeros(4096, np.int32); wq[:w.size] = w
+        _check_ints(q[i].reshape(-1), wq, f"hop q f{i}")
+    # decode the reference's own integers, cross-fade on the device, compare with the reference decoder's PCM
+    want = arr["p1_lv20_decoded"]
+    qs = np.stack([np.pad(g4[f"lv20_f{i}_q"], (0, 4096 - g4[f"lv20_f{i}_q"].size)) for i in range(3)]).reshape(3, 2048, 2)
+    ts = np.stack([np.pad(g4[f"lv20_f{i}_tq"], (0, 54 - g4[f"lv20_f{i}_tq"].size)) for i in range(3)]).reshape(3, 27, 2)
+    dec = be.p1_digital(qs.astype(np.int32), ts.astype(np.int32), 2048, 2, 16, 48000)
+    out, tail = be.p1_ola(dec, 16)
+    got = out.reshape(-1, 2)
+    assert np.max(np.abs(got - want[:got.shape[0]])) <= 1e-12
+    psnr = 10 * np.log10(1.0 / max(np.mean((got - want[:got.shape[0]]) ** 2), 1e-300))
+    assert psnr > 200
+    # second batch continues from the first one's tail
+    out2, tail2 = be.p1_ola(dec[2:3], 16, prev_tail=dec[1, 1920:])
+    assert np.max(np.abs(out2[0] - out[2])) == 0.0
+
+
+def test_p1_float_pcm_is_refused_loudly(be):
+    from frad_python_amd._lib import FradError
+    raw = np.zeros((2048, 2), np.float32)
+    with pytest.raises(FradError):
+        be.p1_analogue(raw, "f32le", 1, 2048, 2, 16, 48000, 1.0)
