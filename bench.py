@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from frad_python_amd import core  # noqa: E402
+from frad_python_amd.parallel import Timer  # noqa: E402
 
 SRATE, CHANNELS, FSIZE, BITS = 48000, 2, 2048, 32
 SECONDS = 600
@@ -138,28 +139,19 @@ def main():
 
     wl = Workload(dev, seed=1234 + rank)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         wl.encode(); wl.decode(); wl.overflow_check()
     ev_enc = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     ev_dec = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        wl.encode(ev_enc[i])
-        wl.decode(ev_dec[i])
-        wl.overflow_check()
-    barrier()
-    elapsed = time.perf_counter() - t0
+
+    def timed_steps():
+        for i in range(args.steps):
+            wl.encode(ev_enc[i])
+            wl.decode(ev_dec[i])
+            wl.overflow_check()
+    # barrier + torch.cuda.synchronize() on both sides of exactly K steps, MAX over ranks (parallel.Timer)
+    elapsed = Timer(dist, torch.cuda.synchronize).measure(timed_steps)
     assert not bool(wl.over), "synthetic audio must not overflow float32 storage"
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
 
     enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_enc]))
     dec_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_dec]))

@@ -1,0 +1,66 @@
+"""Host <-> device bridge used by the streaming Encoder / Decoder.
+
+``HipBridge`` moves a batch of frames (host bytes / ndarrays, as the reference's streaming API hands
+them over) through the HIP transform core: one H2D copy, one launch per homogeneous batch, one D2H
+copy.  The Encoder / Decoder only depend on this small interface, which lets the CPU-only test-suite
+drive their host logic (frame cut, overlap carry, ASFH, CRC) with a bridge of its own; the default
+-- and the only one in this package -- is the HIP one: there is no CPU fallback."""
+from __future__ import annotations
+
+import numpy as np
+
+
+class HipBridge:
+    def __init__(self, device=None):
+        import torch
+        from . import core
+        if not torch.cuda.is_available():
+            raise RuntimeError("the FrAD transform core needs an MI355X (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.torch, self.core = torch, core
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+    def _up(self, data: bytes):
+        return self.torch.frombuffer(bytearray(data), dtype=self.torch.uint8).to(self.device) if len(data) else \
+            self.torch.empty(0, dtype=self.torch.uint8, device=self.device)
+
+    def lossless_encode(self, profile, pcm: bytes, fmt, n_frames, N, C, bits, little_endian, raw_be_ints=True):
+        """-> list of (payload bytes, bits actually used) per frame."""
+        enc = self.core.analogue_batch(profile, self._up(pcm), fmt, n_frames, N, C, bits, little_endian,
+                                       raw_be_ints=raw_be_ints)
+        host = enc.payload[:, :enc.nbytes].cpu().numpy()
+        out = []
+        for i in range(n_frames):
+            if i in enc.escalated:
+                row, b = enc.escalated[i]
+                out.append((bytes(row.cpu().numpy()), b))
+            else:
+                out.append((host[i].tobytes(), enc.bits))
+        return out
+
+    def lossless_decode(self, profile, payloads: list, N, C, bits, little_endian) -> np.ndarray:
+        n = len(payloads)
+        nb = len(payloads[0])
+        stride = (nb + 15) // 16 * 16
+        host = np.zeros((n, stride), np.uint8)
+        for i, p in enumerate(payloads):
+            host[i, :nb] = np.frombuffer(p, np.uint8)
+        dev = self.torch.from_numpy(host).to(self.device)
+        return self.core.digital_batch(profile, dev, n, N, C, bits, little_endian).cpu().numpy()
+
+    def p1_encode(self, pcm: bytes, fmt, n_frames, N, C, bits, srate, loss_level, hop, n_valid, raw_be_ints=True):
+        q, tq = self.core.p1_analogue_batch(self._up(pcm), fmt, n_frames, N, C, bits, srate, loss_level,
+                                            frame_stride=hop, n_valid=n_valid, raw_be_ints=raw_be_ints)
+        return q.cpu().numpy(), tq.cpu().numpy()
+
+    def p1_decode(self, q: np.ndarray, tq: np.ndarray, N, C, bits, srate) -> np.ndarray:
+        t = self.torch
+        return self.core.p1_digital_batch(t.from_numpy(np.ascontiguousarray(q, np.int32)).to(self.device),
+                                          t.from_numpy(np.ascontiguousarray(tq, np.int32)).to(self.device),
+                                          N, C, bits, srate).cpu().numpy()
+
+    def overlap_add(self, frames: np.ndarray, ratio: int, prev_tail):
+        t = self.torch
+        pt = t.from_numpy(np.ascontiguousarray(prev_tail)).to(self.device) if prev_tail is not None else None
+        out, nxt = self.core.p1_overlap_add(t.from_numpy(np.ascontiguousarray(frames)).to(self.device), ratio, pt)
+        return out.cpu().numpy(), nxt.cpu().numpy()

@@ -1,0 +1,185 @@
+"""Streaming decoder with the reference's API (src/libfrad/decoder.py): ``Decoder(fix_error)``,
+``process(bytes) -> DecodeResult``, ``flush()``, ``is_empty()``, ``get_asfh()``.  Frame headers are parsed
+on the host exactly as the reference does; runs of consecutive frames with identical geometry are then
+decoded by ONE launch of the HIP transform core (the reference decodes one frame per loop iteration,
+decoder.py:55-80), and the compact profiles' Hann cross-fade runs on the device as well."""
+from __future__ import annotations
+
+import struct
+import zlib
+
+import numpy as np
+
+from . import common
+from .fourier import profiles
+from .fourier.tools import p1tools
+from .tools.asfh import ASFH
+
+_LOSSLESS_DEPTHS = (12, 16, 24, 32, 48, 64)
+_P1_DEPTHS = (8, 12, 16, 24, 32, 48, 64)
+
+
+class DecodeResult:
+    def __init__(self, pcm: list, srate: int, frames: int, crit: bool):
+        pcm = [p for p in pcm if p.size]
+        self.pcm = np.concatenate(pcm) if pcm else np.array([])
+        self.srate = srate
+        self.frames = frames
+        self.crit = crit
+
+
+def _strip_ecc(frad: bytes, dsize: int, codesize: int) -> bytes:
+    """tools/ecc.py:14-25 with repair off: drop the Reed-Solomon code bytes of every block."""
+    block = dsize + codesize
+    return b"".join(frad[i:i + block][:max(len(frad[i:i + block]) - codesize, 0)] for i in range(0, len(frad), block))
+
+
+class Decoder:
+    def __init__(self, fix_error: bool = False, *, bridge=None):
+        if fix_error:
+            raise NotImplementedError("Reed-Solomon repair is host-side and needs the third-party reedsolo module; "
+                                      "it is outside the MI355X transform core")
+        self.asfh = ASFH()
+        self.info = ASFH()
+        self.buffer = b""
+        self.overlap_fragment = np.array([])          # tail of the last compact frame, [L, C]
+        self.fix_error = fix_error
+        self.broken_frame = False
+        self._bridge = bridge
+
+    @property
+    def bridge(self):
+        if self._bridge is None:
+            from .bridge import HipBridge
+            self._bridge = HipBridge()
+        return self._bridge
+
+    def is_empty(self) -> bool:
+        return len(self.buffer) < len(common.FRM_SIGN) or self.broken_frame
+
+    def get_asfh(self) -> ASFH:
+        return self.asfh
+
+    # ------------------------------------------------------------------ batched decode of one run of frames
+    def _decode_run(self, key, payloads: list) -> list:
+        profile, fsize, channels, depth_idx, endian, srate, ratio = key
+        if profile == 1:
+            bits = _P1_DEPTHS[depth_idx]
+            qs = np.zeros((len(payloads), fsize * channels), np.int32)
+            ts = np.zeros((len(payloads), 27 * channels), np.int32)
+            bad = []
+            for i, frad in enumerate(payloads):
+                try:
+                    raw = zlib.decompress(frad, wbits=-15)
+                except Exception:
+                    bad.append(i)                                   # profile1.py:59-60 -> a frame of zeros
+                    continue
+                tl = struct.unpack(">I", raw[:4])[0]
+                t = p1tools.exp_golomb_rice_decode(raw[4:4 + tl])[:27 * channels]
+                q = p1tools.exp_golomb_rice_decode(raw[4 + tl:])[:fsize * channels]
+                ts[i, :t.size], qs[i, :q.size] = t, q
+            pcm = self.bridge.p1_decode(qs.reshape(-1, fsize, channels), ts.reshape(-1, 27, channels), fsize, channels, bits, srate)
+            for i in bad:
+                pcm[i] = 0.0
+        else:
+            pcm = self.bridge.lossless_decode(profile, payloads, fsize, channels, _LOSSLESS_DEPTHS[depth_idx], endian)
+        if profile in profiles.COMPACT and ratio != 0:
+            # Hann cross-fade against the previous frame's tail (decoder.py:28-46) on the device
+            L = fsize - fsize * (ratio - 1) // ratio
+            prev = self.overlap_fragment if self.overlap_fragment.shape == (L, channels) else None
+            if prev is None and self.overlap_fragment.size:
+                return self._overlap_host(pcm, key)                 # geometry changed between frames: rare, host path
+            out, tail = self.bridge.overlap_add(pcm, ratio, prev)
+            self.overlap_fragment = tail
+            return list(out)
+        if self.overlap_fragment.size:
+            return self._overlap_host(pcm, key)
+        return list(pcm)
+
+    def _overlap_host(self, pcm: np.ndarray, key) -> list:
+        """decoder.py:28-46 verbatim semantics for the odd cases (fragment of another length)."""
+        profile, fsize, channels, depth_idx, endian, srate, ratio = key
+        out = []
+        prog = 0
+        for frame in pcm:
+            frame = frame.copy()
+            L = len(self.overlap_fragment)
+            if L:
+                w = 0.5 * (1 - np.cos(np.pi * np.arange(1, L + 1) / (L + 1)))
+                n = min(L - prog, len(frame))
+                i = np.arange(n) + prog
+                frame[:n] = frame[:n] * w[i, None] + self.overlap_fragment[i] * w[L - 1 - i, None]
+                prog += n
+            if L <= prog:
+                self.overlap_fragment, prog = np.array([]), 0
+                if profile in profiles.COMPACT and ratio != 0:
+                    cut = len(frame) * (ratio - 1) // ratio
+                    self.overlap_fragment, frame = frame[cut:], frame[:cut]
+            out.append(frame)
+        return out
+
+    # ------------------------------------------------------------------ the reference's process() loop, batched
+    def process(self, stream: bytes) -> DecodeResult:
+        self.buffer += stream
+        ret_pcm, frames = [], 0
+        run_key, run = None, []
+
+        def close_run():
+            nonlocal run_key, run
+            if run:
+                ret_pcm.extend(self._decode_run(run_key, run))
+            run_key, run = None, []
+
+        while True:
+            if self.asfh.all_set:
+                self.broken_frame = False
+                if len(self.buffer) < self.asfh.frmbytes:
+                    if len(stream) == 0:
+                        self.broken_frame = True
+                    break
+                frad, self.buffer = self.buffer[:self.asfh.frmbytes], self.buffer[self.asfh.frmbytes:]
+                a = self.asfh
+                if a.ecc:
+                    frad = _strip_ecc(frad, a.ecc_dsize, a.ecc_codesize)
+                key = (a.profile, a.fsize, a.channels, a.bit_depth_index, a.endian, a.srate, a.overlap_ratio)
+                if a.profile not in (0, 1, 4):
+                    raise NotImplementedError(f"profile {a.profile} is not built (upstream: in development)")
+                if key != run_key or (run and len(frad) != len(run[0]) and a.profile != 1):
+                    close_run()
+                    run_key = key
+                run.append(frad)
+                frames += 1
+                self.asfh.clear()
+            else:
+                if not self.asfh.buffer[:len(common.FRM_SIGN)] == common.FRM_SIGN:
+                    i = self.buffer.find(common.FRM_SIGN)
+                    if i != -1:
+                        self.buffer = self.buffer[i:]
+                        self.asfh.buffer = self.buffer[:len(common.FRM_SIGN)]
+                        self.buffer = self.buffer[len(common.FRM_SIGN):]
+                    else:
+                        self.buffer = self.buffer[-len(common.FRM_SIGN) + 1:]
+                        break
+                header_result, self.buffer = self.asfh.read(self.buffer)
+                if header_result == "Complete":
+                    if not self.asfh.criteq(self.info):
+                        srate, chnl = self.info.srate, self.info.channels
+                        self.info = self.asfh
+                        if srate or chnl:
+                            close_run()
+                            ret_pcm.append(self.flush().pcm)
+                            return DecodeResult(ret_pcm, srate, frames, True)
+                elif header_result == "ForceFlush":
+                    close_run()
+                    ret_pcm.append(self.flush().pcm)
+                    break
+                else:
+                    break
+        close_run()
+        return DecodeResult(ret_pcm, self.asfh.srate, frames, False)
+
+    def flush(self) -> DecodeResult:
+        ret = self.overlap_fragment
+        self.overlap_fragment = np.array([])
+        self.asfh.clear()
+        return DecodeResult([ret], self.asfh.srate, 0, False)

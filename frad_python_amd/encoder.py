@@ -1,0 +1,226 @@
+"""Streaming encoder with the reference's API (src/libfrad/encoder.py): same constructor, setters,
+``process(bytes) -> EncodeResult`` and ``flush()``, byte-identical streams -- but every ``process`` call
+hands ALL the whole frames it holds to the HIP transform core in one batched launch instead of looping
+one frame at a time through NumPy (encoder.py:60-105).  ASFH framing and CRC stay on the host."""
+from __future__ import annotations
+
+import struct
+import sys
+import zlib
+
+import numpy as np
+
+from .backend.pcmformat import ff_format_to_numpy_type
+from .fourier import AVAILABLE, BIT_DEPTHS, SEGMAX, profiles
+from .fourier.profiles import compact
+from .fourier.tools import p1tools
+from .tools.asfh import ASFH
+
+_LOSSLESS_DEPTHS = (12, 16, 24, 32, 48, 64)
+_P1_DEPTHS = (8, 12, 16, 24, 32, 48, 64)
+
+
+class EncodeResult:
+    def __init__(self, buf: bytes, samples: int):
+        self.buf = buf
+        self.samples = samples
+
+
+class Encoder:
+    def __init__(self, profile: int, srate: int, channels: int, bit_depth: int, frame_size: int, pcm_format: str, *, bridge=None):
+        if profile not in AVAILABLE:
+            print(f"Invalid profile! Available: {AVAILABLE}", file=sys.stderr)
+            sys.exit(1)
+        self.asfh = ASFH()
+        self.buffer = b""
+        self.bit_depth = self.channels = self.fsize = self.srate = 0
+        self.pcm_format_name = pcm_format
+        self.pcm_format = ff_format_to_numpy_type(pcm_format)
+        self.loss_level = 0.5
+        self.init = False
+        self.have_carry = False          # compact profiles: the head of `buffer` is the previous frame's tail
+        self._bridge = bridge
+        self.set_profile(profile, srate, channels, bit_depth, frame_size)
+
+    # ------------------------------------------------------------------ device access
+    @property
+    def bridge(self):
+        if self._bridge is None:
+            from .bridge import HipBridge
+            self._bridge = HipBridge()
+        return self._bridge
+
+    # ------------------------------------------------------------------ framing helpers
+    def _emit(self, frad: bytes, depth_idx: int, fsize: int) -> bytes:
+        if self.asfh.ecc:
+            raise NotImplementedError("Reed-Solomon ECC is host-side and not part of the MI355X transform core")
+        a = self.asfh
+        a.bit_depth_index, a.channels, a.fsize = depth_idx, self.channels, fsize
+        a.srate = compact.get_valid_srate(self.srate) if a.profile in profiles.COMPACT else self.srate
+        return a.write(frad)
+
+    def _p1_pack(self, q: np.ndarray, tq: np.ndarray) -> bytes:
+        tg = p1tools.exp_golomb_rice_encode(tq)
+        fg = p1tools.exp_golomb_rice_encode(q)
+        co = zlib.compressobj(zlib.Z_DEFAULT_COMPRESSION, zlib.DEFLATED, -15)     # profile1.py:50 wbits=-15
+        return co.compress(struct.pack(">I", len(tg)) + tg + fg) + co.flush()
+
+    def _encode_frames(self, pcm: bytes, n_frames: int, n_eff: int, hop: int, n_valid: int) -> bytes:
+        """n_frames frames of n_eff sample-frames, frame i starting i*hop sample-frames into `pcm`."""
+        prof, C = self.asfh.profile, self.channels
+        out = []
+        if prof == 1:
+            bits = self.bit_depth if self.bit_depth in _P1_DEPTHS else 16
+            N = compact.get_samples_min_ge(n_eff)
+            q, tq = self.bridge.p1_encode(pcm, self.pcm_format_name, n_frames, N, C, bits, compact.get_valid_srate(self.srate),
+                                          self.loss_level, hop, n_valid)
+            for i in range(n_frames):
+                out.append(self._emit(self._p1_pack(q[i].reshape(-1), tq[i].reshape(-1)), _P1_DEPTHS.index(bits), n_valid))
+        else:
+            bits = self.bit_depth if self.bit_depth in _LOSSLESS_DEPTHS else 16
+            for frad, used in self.bridge.lossless_encode(prof, pcm, self.pcm_format_name, n_frames, n_eff, C, bits, self.asfh.endian):
+                out.append(self._emit(frad, _LOSSLESS_DEPTHS.index(used), n_eff))
+        return b"".join(out)
+
+    def inner(self, stream: bytes, flush: bool) -> EncodeResult:
+        self.buffer += stream
+        if not self.init:
+            return EncodeResult(b"", 0)
+        compact_prof = self.asfh.profile in profiles.COMPACT
+        n_eff = compact.get_samples_min_ge(self.fsize) if compact_prof else self.fsize
+        ratio = self.asfh.overlap_ratio
+        cut = n_eff * (ratio - 1) // ratio if (compact_prof and ratio > 1) else n_eff      # encoder.py:48
+        step = self.pcm_format.itemsize * self.channels
+        have = len(self.buffer) // step
+        ret, samples = b"", 0
+        # ---- whole frames (encoder.py:72-104, batched): frame i covers sample-frames [i*cut, i*cut + n_eff)
+        if have >= n_eff:
+            k = (have - n_eff) // cut + 1
+            ret += self._encode_frames(self.buffer[:((k - 1) * cut + n_eff) * step], k, n_eff, cut, n_eff)
+            carry = n_eff - cut
+            samples += k * n_eff - (k - 1) * carry - (carry if self.have_carry else 0)
+            self.buffer = self.buffer[k * cut * step:]
+            self.have_carry = carry > 0
+        if not flush:
+            return EncodeResult(ret, samples)
+        # ---- flush (encoder.py:81, 89-91, 105): what is left (carry + remainder) becomes one short frame
+        have = len(self.buffer) // step
+        if have > 0:
+            carry = (n_eff - cut) if self.have_carry else 0
+            ret += self._encode_frames(self.buffer[:have * step], 1, have, have, have)
+            samples += have - carry
+            ret += self.asfh.force_flush()
+        self.buffer, self.have_carry = b"", False
+        ret += self.asfh.force_flush()
+        return EncodeResult(ret, samples)
+
+    def process(self, stream: bytes) -> EncodeResult:
+        return self.inner(stream, False)
+
+    def flush(self) -> EncodeResult:
+        return self.inner(b"", True) if self.init else EncodeResult(b"", 0)
+
+    # ------------------------------------------------------------------ getters / setters (encoder.py:114-215)
+    @staticmethod
+    def verify_profile(profile):
+        return None if profile in AVAILABLE else f"Invalid profile! Available: {AVAILABLE}"
+
+    @staticmethod
+    def verify_srate(profile, srate):
+        if srate == 0:
+            return "Sample rate cannot be zero"
+        if profile in profiles.COMPACT and compact.get_valid_srate(srate) != srate:
+            return f"Invalid sample rate! Valid rates for profile {profile}: {compact.SRATES}"
+        return None
+
+    @staticmethod
+    def verify_channels(profile, channels):
+        return "Channel count cannot be zero" if channels == 0 else None
+
+    @staticmethod
+    def verify_bit_depth(profile, bit_depth):
+        if bit_depth == 0:
+            return "Bit depth cannot be zero"
+        if bit_depth not in BIT_DEPTHS[profile]:
+            return f"Invalid bit depth! Valid depths for profile {profile}: {list(BIT_DEPTHS[profile])}"
+        return None
+
+    @staticmethod
+    def verify_frame_size(profile, frame_size):
+        if frame_size == 0:
+            return "Frame size cannot be zero"
+        if frame_size > SEGMAX[profile]:
+            return f"Samples per frame cannot exceed {SEGMAX[profile]}"
+        return None
+
+    def get_profile(self):
+        return self.asfh.profile
+
+    def set_profile(self, profile, srate, channels, bit_depth, frame_size):
+        for e in (self.verify_profile(profile), self.verify_srate(profile, srate), self.verify_channels(profile, channels),
+                  self.verify_bit_depth(profile, bit_depth), self.verify_frame_size(profile, frame_size)):
+            if e is not None:
+                return e
+        res = EncodeResult(b"", 0)
+        if (self.channels != 0 and self.channels != channels) or (self.srate != 0 and self.srate != srate):
+            res = self.flush()
+        self.asfh.profile = profile
+        self.srate, self.channels, self.bit_depth, self.fsize = srate, channels, bit_depth, frame_size
+        self.init = True
+        return res
+
+    def get_channels(self):
+        return self.channels
+
+    def set_channels(self, channels):
+        res = EncodeResult(b"", 0)
+        if self.channels != 0 and self.channels != channels:
+            res = self.flush()
+        self.channels = channels
+        return res
+
+    def get_srate(self):
+        return self.srate
+
+    def set_srate(self, srate):
+        if e := self.verify_srate(self.get_profile(), srate):
+            return e
+        res = EncodeResult(b"", 0)
+        if self.srate != 0 and self.srate != srate:
+            res = self.flush()
+        self.srate = srate
+        return res
+
+    def get_frame_size(self):
+        return self.fsize
+
+    def set_frame_size(self, frame_size):
+        if e := self.verify_frame_size(self.get_profile(), frame_size):
+            return e
+        self.fsize = frame_size
+
+    def get_bit_depth(self):
+        return self.bit_depth
+
+    def set_bit_depth(self, bit_depth):
+        if e := self.verify_bit_depth(self.get_profile(), bit_depth):
+            return e
+        self.bit_depth = bit_depth
+
+    def set_ecc(self, ecc: bool, ecc_ratio):
+        if ecc:
+            raise NotImplementedError("Reed-Solomon ECC is host-side and not part of the MI355X transform core "
+                                      "(the reference needs the third-party reedsolo module for it)")
+        self.asfh.ecc = False
+        self.asfh.ecc_dsize, self.asfh.ecc_codesize = ecc_ratio if ecc_ratio[0] and sum(ecc_ratio) <= 255 else (96, 24)
+
+    def set_little_endian(self, little_endian: bool):
+        self.asfh.endian = little_endian
+
+    def set_loss_level(self, loss_level: float):
+        self.loss_level = max(abs(loss_level), 0.125)
+
+    def set_overlap_ratio(self, overlap_ratio: int):
+        if overlap_ratio != 0:
+            overlap_ratio = max(2, min(256, overlap_ratio))
+        self.asfh.overlap_ratio = overlap_ratio

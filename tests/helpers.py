@@ -194,3 +194,52 @@ def unpack12(buf: np.ndarray) -> np.ndarray:
 
 def payload_values(fo, buf: np.ndarray, bits: int, le: bool) -> np.ndarray:
     return fo.unpack_floats(buf.tobytes(), bits, le)
+
+
+class OracleBridge:
+    """TEST-ONLY stand-in for frad_python_amd.bridge.HipBridge: the oracle does the arithmetic, so that
+    the CPU suite can check the Encoder / Decoder host logic (frame cut, overlap carry, ASFH, CRC, Golomb)
+    byte-for-byte against the reference-generated streams.  Never importable from the product package."""
+
+    def __init__(self):
+        from oracle import frad_oracle as fo
+        self.fo = fo
+
+    def lossless_encode(self, profile, pcm, fmt, n_frames, N, C, bits, little_endian, raw_be_ints=True):
+        fo = self.fo
+        dt = fo.pcm_dtype(fmt)
+        x = np.frombuffer(pcm, dt, n_frames * N * C).reshape(n_frames, N, C)
+        out = []
+        for f in range(n_frames):
+            frame = fo.to_f64(x[f], dt, be_int_quirk=raw_be_ints)
+            frad, idx, ch, sr = (fo.p4_analogue if profile == 4 else fo.p0_analogue)(frame, bits, 0, little_endian)
+            out.append((frad, fo.DEPTHS[idx]))
+        return out
+
+    def lossless_decode(self, profile, payloads, N, C, bits, little_endian):
+        fo = self.fo
+        dig = fo.p4_digital if profile == 4 else fo.p0_digital
+        return np.stack([dig(p, fo.DEPTHS.index(bits), C, little_endian) for p in payloads])
+
+    def p1_encode(self, pcm, fmt, n_frames, N, C, bits, srate, loss_level, hop, n_valid, raw_be_ints=True):
+        fo = self.fo
+        dt = fo.pcm_dtype(fmt)
+        x = np.frombuffer(pcm, dt).reshape(-1, C)
+        q = np.zeros((n_frames, N, C), np.int32); tq = np.zeros((n_frames, 27, C), np.int32)
+        for f in range(n_frames):
+            a, b, aux = fo.p1_analogue_pre(fo.to_f64(x[f * hop:f * hop + n_valid], dt, be_int_quirk=raw_be_ints), bits, srate, loss_level)
+            q[f] = a.reshape(N, C); tq[f] = b.reshape(27, C)
+        return q, tq
+
+    def p1_decode(self, q, tq, N, C, bits, srate):
+        fo = self.fo
+        return np.stack([fo.p1_digital_post(q[i].reshape(-1), tq[i].reshape(-1), fo.P1_DEPTHS.index(bits), C, srate, N)
+                         for i in range(len(q))])
+
+    def overlap_add(self, frames, ratio, prev_tail):
+        fo = self.fo
+        ola = fo.OverlapAdd()
+        if prev_tail is not None:
+            ola.fragment = np.array(prev_tail)
+        out = [ola.push(f.copy(), True, ratio) for f in frames]
+        return np.stack(out), ola.fragment

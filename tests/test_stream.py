@@ -1,0 +1,111 @@
+"""Drop-in boundary: the reference's streaming API (Encoder.process/flush, Decoder.process/flush)
+reproduced byte-for-byte.  Golden streams come from the reference itself (tests/golden/g3_*).
+
+CPU leg ("host"): the product Encoder/Decoder with the TEST bridge (oracle arithmetic) -- checks the
+host logic only.  GPU leg: the same objects on the HIP transform core (the product path)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_json, load_npz
+from frad_python_amd import Decoder, Encoder, synth
+from oracle import frad_oracle as fo
+
+
+def _bridge(kind):
+    if kind == "host":
+        from helpers import OracleBridge
+        return OracleBridge()
+    from frad_python_amd.bridge import HipBridge
+    return HipBridge()
+
+
+@pytest.fixture(params=[pytest.param("host"), pytest.param("gpu", marks=pytest.mark.gpu)])
+def kind(request):
+    return request.param
+
+
+def _inputs():
+    return {
+        "cfg1": synth.sine(48000, 1, 48000, 440.0, 0.5).astype(">f8").tobytes(),
+        "tiny": np.array([0.25, -0.5, 0.75, 0.125]).astype(">f8").tobytes(),
+        "st": synth.to_pcm(synth.harmonic_mix(3000, 2, 44100, seed=3), "s16le").tobytes(),
+        "p1": load_npz("g3_p1_streams.npz")["p1_input_s16le"].tobytes(),
+    }
+
+
+def _encode(kind, pcm, chunk, p):
+    enc = Encoder(p["profile"], p["srate"], p["channels"], p["bits"], p["frame_size"], p["pcm_format"], bridge=_bridge(kind))
+    enc.set_little_endian(p.get("little_endian", False))
+    enc.set_overlap_ratio(p.get("overlap_ratio", 0))
+    enc.set_loss_level(p.get("loss_level", 0.5))
+    out, samples = b"", 0
+    for i in range(0, len(pcm), chunk):
+        r = enc.process(pcm[i:i + chunk]); out += r.buf; samples += r.samples
+    r = enc.flush(); out += r.buf; samples += r.samples
+    return out, samples
+
+
+def _decode(kind, stream, chunk, channels):
+    dec = Decoder(bridge=_bridge(kind))
+    pcm, frames = [], 0
+    for i in range(0, len(stream), chunk):
+        d = dec.process(stream[i:i + chunk]); pcm.append(d.pcm.reshape(-1, channels)); frames += d.frames
+    pcm.append(dec.flush().pcm.reshape(-1, channels))
+    return np.concatenate(pcm), frames
+
+
+def test_streams_encode_byte_for_byte_and_decode(kind):
+    g3, inputs = load_json("g3_streams.json"), _inputs()
+    arr = load_npz("g3_p1_streams.npz")
+    for c in g3["cases"]:
+        p = c["params"]
+        pcm = inputs[c["name"].split("_")[0]]
+        lossy = p["profile"] == 1
+        for chunk in ((32768, 1000) if not lossy else (4096,)):
+            out, samples = _encode(kind, pcm, chunk, p)
+            assert samples == c["samples"], c["name"]
+            assert len(out) == c["nbytes"] or (kind == "gpu" and lossy), c["name"]
+            if kind == "host" or p["profile"] == 4:
+                assert hashlib.sha256(out).hexdigest() == c["sha256"], (c["name"], chunk)
+            elif not lossy:
+                # profile 0 on the GPU: payload words identical up to rare double-rounding ties -> compare values
+                ref = fo.encode_stream(pcm, **p)
+                a, b = np.frombuffer(out, np.uint8), np.frombuffer(ref, np.uint8)
+                assert a.size == b.size and np.count_nonzero(a != b) <= max(8, a.size * 1e-4), c["name"]
+        # decode the REFERENCE stream
+        ref_stream = arr[f"{c['name']}_stream"].tobytes() if lossy else fo.encode_stream(pcm, **p)
+        got, frames = _decode(kind, ref_stream, 777, p["channels"])
+        want = fo.decode_stream(ref_stream)
+        assert frames == c["frames"] and list(got.shape) == c["decoded_shape"], c["name"]
+        if kind == "host" or p["profile"] == 4:
+            assert hashlib.sha256(np.ascontiguousarray(got).astype("<f8").tobytes()).hexdigest() == c["decoded_sha256"], c["name"]
+        else:
+            assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, np.max(np.abs(want))), c["name"]
+
+
+def test_encoder_rejects_like_the_reference(kind):
+    # bits = 0 (the CLI default) fails verify_bit_depth: the reference's constructor ignores the error string
+    # and the encoder then silently emits nothing (encoder.py:33, 57-58, 139-140)
+    enc = Encoder(4, 48000, 2, 0, 2048, "s16le", bridge=_bridge(kind))
+    assert enc.process(b"\x00" * 65536).buf == b"" and enc.flush().buf == b""
+    assert isinstance(Encoder(0, 48000, 2, 16, 2048, "s16le", bridge=_bridge(kind)).set_bit_depth(13), str)
+    with pytest.raises(SystemExit):
+        Encoder(2, 48000, 2, 16, 2048, "s16le")
+    with pytest.raises(SystemExit):
+        Encoder(0, 48000, 2, 16, 2048, "s17le")
+    with pytest.raises(NotImplementedError):
+        Encoder(0, 48000, 2, 16, 2048, "s16le", bridge=_bridge(kind)).set_ecc(True, (96, 24))
+
+
+def test_decoder_resync_and_truncation(kind):
+    pcm = synth.to_pcm(synth.harmonic_mix(5000, 2, 48000, seed=1), "s16le").tobytes()
+    p = dict(profile=4, srate=48000, channels=2, bits=16, frame_size=1024, pcm_format="s16le")
+    stream, _ = _encode(kind, pcm, 4096, p)
+    want = fo.decode_stream(stream)
+    dec = Decoder(bridge=_bridge(kind))
+    d = dec.process(b"garbage-before-the-first-frame" + stream[:-100])
+    assert d.frames == 4 and not dec.is_empty()
+    assert np.array_equal(d.pcm, want[:4 * 1024])
+    assert dec.process(b"").frames == 0 and dec.broken_frame and dec.is_empty()
