@@ -73,7 +73,11 @@ def test_streams_encode_byte_for_byte_and_decode(kind):
                 # profile 0 on the GPU: payload words identical up to rare double-rounding ties -> compare values
                 ref = fo.encode_stream(pcm, **p)
                 a, b = np.frombuffer(out, np.uint8), np.frombuffer(ref, np.uint8)
-                assert a.size == b.size and np.count_nonzero(a != b) <= max(8, a.size * 1e-4), c["name"]
+                assert a.size == b.size, c["name"]
+                if p["bits"] <= 32:                      # stored words bit-identical up to rare rounding ties (+ their CRCs)
+                    assert np.count_nonzero(a != b) <= max(16, a.size * 1e-4), c["name"]
+                # any depth: what the stream decodes to (through the oracle) is the reference's PCM
+                assert np.max(np.abs(fo.decode_stream(out) - fo.decode_stream(ref))) <= 1e-12, c["name"]
         # decode the REFERENCE stream
         ref_stream = arr[f"{c['name']}_stream"].tobytes() if lossy else fo.encode_stream(pcm, **p)
         got, frames = _decode(kind, ref_stream, 777, p["channels"])

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>_* (rocprofv3 CSVs) into the small, committed files under profiles/:
+   <tag>_kernel_stats.csv   the --stats table, FrAD kernels only (+ everything else summed)
+   <tag>_counters.json      per-kernel means of the PMC passes, HBM traffic with the gfx950 FETCH_SIZE x2
+                            correction of MI355X_MICROARCH.md (FETCH_SIZE tallies 128-B requests at 64 B)
+Usage: python tools/summarise_profiles.py r01"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(src, pattern))
+    return g[0] if g else None
+
+
+stats = one(f"prof_{tag}_trace/*/*_kernel_stats.csv")
+if stats:
+    rows = list(csv.DictReader(open(stats)))
+    keep = [r for r in rows if "frad::" in r["Name"]]
+    other = [r for r in rows if "frad::" not in r["Name"]]
+    with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in keep:
+            w.writerow([r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")])
+        w.writerow(["(all other kernels: torch workload synthesis, overflow flag, memsets)", sum(int(r["Calls"]) for r in other),
+                    sum(int(r["TotalDurationNs"]) for r in other), "", round(sum(float(r["Percentage"]) for r in other), 2), "", "", ""])
+
+counters = {}
+for leg in ("fetch", "write", "sq"):
+    f = one(f"prof_{tag}_{leg}/*/*_counter_collection.csv")
+    if not f:
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    for r in csv.DictReader(open(f)):
+        if "frad::" not in r["Kernel_Name"]:
+            continue
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        meta[r["Kernel_Name"]] = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "Grid_Size", "Workgroup_Size")}
+    for k, d in agg.items():
+        e = counters.setdefault(k, {"launch": meta[k]})
+        for c, v in d.items():
+            e[c] = sum(v) / len(v)
+for k, e in counters.items():
+    if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+        # units: KiB per dispatch; FETCH_SIZE under-counts wide coalesced reads by exactly 2x on gfx950
+        e["hbm_bytes_per_launch_corrected"] = int((2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024)
+        e["hbm_bytes_per_launch_raw"] = int((e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024)
+json.dump(counters, open(os.path.join(dst, f"{tag}_counters.json"), "w"), indent=1)
+print("wrote", [f for f in os.listdir(dst) if f.startswith(tag)])
