@@ -163,8 +163,19 @@ def main():
         return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": nbytes,
                 "avg_launch_ms": round(ms, 4)}
-    r_enc = roof("k_p0_fwd<double,10,1> (load+to_f64+DCT-II+absmax+f32 cast+BE pack)", enc_bytes, enc_ms)
-    r_dec = roof("k_p0_inv<10> (unpack+scrub+inverse DCT+f64 interleaved store)", dec_bytes, dec_ms)
+    r_enc = roof("k_p0_fwd_unit<double,PlanA10,s16,C=2> (load+to_f64+DCT-II+absmax+f32 cast+BE pack)", enc_bytes, enc_ms)
+    r_dec = roof("k_p0_inv_unit<PlanA10,32,C=2> (unpack+scrub+inverse DCT+f64 interleaved store)", dec_bytes, dec_ms)
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this round (profiles/, collected with
+    # tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE x2 as the gfx950 guide prescribes)
+    try:
+        cnt = json.load(open(os.path.join(ROOT, "profiles", "r01_counters.json")))
+        for r, key in ((r_enc, "k_p0_fwd"), (r_dec, "k_p0_inv")):
+            hit = [v for k, v in cnt.items() if key in k and v.get("launch", {}).get("Grid_Size") and "hbm_bytes_per_launch_corrected" in v
+                   and int(v["hbm_bytes_per_launch_corrected"]) > 1e8]
+            if hit:
+                r["traffic"] = int(hit[0]["hbm_bytes_per_launch_corrected"])
+    except Exception:
+        pass
     dominant, other = (r_dec, r_enc) if dec_ms >= enc_ms else (r_enc, r_dec)
 
     if rank == 0:

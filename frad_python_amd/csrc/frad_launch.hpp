@@ -23,9 +23,14 @@ int get_tables(int log2m, bool f32, Tables& out);
 int get_direct(int N, DirectTable& out);
 FastCfg fast_cfg(int N, int C, bool f32);
 
+// opt a kernel in to more than 48 KiB of dynamic LDS -- once per kernel and size (the call is host-side
+// work on every launch otherwise, and the GPU idles behind it between the encode and decode kernels)
 template <typename K> inline void allow_lds(K kernel, size_t bytes) {
-    if (bytes > 48 * 1024)
+    static thread_local size_t granted = 0;          // one instance per kernel type K
+    if (bytes > 48 * 1024 && bytes > granted) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        granted = bytes;
+    }
 }
 
 // each returns 0 or FRAD_E_UNSUPPORTED (-2) when that (log2m, lg) is not built
