@@ -119,7 +119,7 @@ def test_cfg5_lossy_profile_sixty_seconds(gpu):
     out, tail = core.p1_overlap_add(dec, 16)
     host = pcm.cpu().numpy()
     differing, total, err = 0, 0, 0.0
-    for f in (0, 1, 1499, F - 1):
+    for f in (0, 1, 750, F - 1):
         wq, wt, aux = fo.p1_analogue_pre(fo.to_f64(host[f * hop:f * hop + N], fo.pcm_dtype("s16le")), 16, srate, loss)
         gq, gt = q[f].cpu().numpy().reshape(-1), tq[f].cpu().numpy().reshape(-1)
         assert np.abs(gq - wq).max() <= 1 and np.abs(gt - wt).max() <= 1
