@@ -12,6 +12,11 @@
 namespace frad {
 
 typedef unsigned long long u64;
+// plain compiler vectors for 8/16-byte global accesses (HIP's uint4/double2 are classes and cannot be
+// accessed through an address-space qualified pointer)
+typedef uint32_t v4u __attribute__((vector_size(16)));
+typedef uint32_t v2u __attribute__((vector_size(8)));
+typedef double v2d __attribute__((vector_size(16)));
 
 // ---------------------------------------------------------------------------------------------
 // bit casts
@@ -47,10 +52,10 @@ __device__ __forceinline__ float f16_bits_to_f32(uint32_t h) {
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 load_raw(const unsigned char* p, int lg) {
     switch (lg) {
-        case 0: return *p;
-        case 1: return *reinterpret_cast<const unsigned short*>(p);
-        case 2: return *reinterpret_cast<const uint32_t*>(p);
-        default: return *reinterpret_cast<const u64*>(p);
+        case 0: return *FRAD_GCPTR(unsigned char, p);
+        case 1: return *FRAD_GCPTR(unsigned short, p);
+        case 2: return *FRAD_GCPTR(uint32_t, p);
+        default: return *FRAD_GCPTR(u64, p);
     }
 }
 

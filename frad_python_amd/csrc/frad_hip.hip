@@ -325,7 +325,6 @@ int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
     if (c.ok) {
         Tables tb; rc = get_tables(c.log2m, f32, tb);
         if (rc != FRAD_OK) return rc;
-        if (absmax) HIPCHK(hipMemsetAsync(absmax, 0, sizeof(double) * (size_t)n_frames, s));
         if (c.cg < C && bits == 12 && ((C & 1) || (c.cg & 1))) return FRAD_E_UNSUPPORTED;
         g.fpb = c.fpb; g.cg = c.cg;
         if (c.cg == C && ai) {                               // quad stage-in needs whole 16-byte rows / row groups
@@ -335,6 +334,7 @@ int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
         if (c.cg == C && ao && C <= 2 && ((long long)N * C) % 32 == 0) g.cc_fast = C;
         dim3 grid((unsigned)((n_frames + c.fpb - 1) / c.fpb));
         if (!launch_p0_fwd_pers(f32, lg, c, s, in, out, absmax, tb, g, ao)) {
+            if (absmax) HIPCHK(hipMemsetAsync(absmax, 0, sizeof(double) * (size_t)n_frames, s));   // atomicMax target
             rc = f32 ? launch_p0_fwd_f32(lg, c, grid, s, in, out, absmax, tb, g, ai, ao)
                      : launch_p0_fwd_f64(lg, c, grid, s, in, out, absmax, tb, g, ai, ao);
             if (rc != FRAD_OK) return rc;

@@ -45,20 +45,20 @@ template <int NW> __device__ __forceinline__ void load_words(const unsigned char
     if constexpr (NW >= 4) {
 #pragma unroll
         for (int i = 0; i < NW / 4; ++i) {
-            const uint4 v = reinterpret_cast<const uint4*>(p)[i];
-            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+            const v4u v = FRAD_GCPTR(v4u, p)[i];
+            w[4 * i] = v[0]; w[4 * i + 1] = v[1]; w[4 * i + 2] = v[2]; w[4 * i + 3] = v[3];
         }
     } else if constexpr (NW == 2) {
-        const uint2 v = *reinterpret_cast<const uint2*>(p); w[0] = v.x; w[1] = v.y;
+        const v2u v = *FRAD_GCPTR(v2u, p); w[0] = v[0]; w[1] = v[1];
     } else {
-        w[0] = *reinterpret_cast<const uint32_t*>(p);
+        w[0] = *FRAD_GCPTR(uint32_t, p);
     }
 }
 template <int NW> __device__ __forceinline__ void store_words(unsigned char* p, const uint32_t (&w)[NW]) {
 #pragma unroll
     for (int i = 0; i < NW / 4; ++i) {
-        uint4 v; v.x = w[4 * i]; v.y = w[4 * i + 1]; v.z = w[4 * i + 2]; v.w = w[4 * i + 3];
-        reinterpret_cast<uint4*>(p)[i] = v;
+        v4u v = {w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
+        FRAD_GPTR(v4u, p)[i] = v;
     }
 }
 // element i (LG = log2 itemsize) of a little-endian word array
@@ -184,8 +184,8 @@ __global__ void __launch_bounds__(256) k_p4_unpack(const unsigned char* __restri
         unpack_unit<BITS>(w, le, codes);
 #pragma unroll
         for (int i = 0; i < U / 2; ++i) {
-            double2 v; v.x = code_to_f64(codes[2 * i], BITS); v.y = code_to_f64(codes[2 * i + 1], BITS);
-            reinterpret_cast<double2*>(dst + u * U)[i] = v;
+            v2d v = {code_to_f64(codes[2 * i], BITS), code_to_f64(codes[2 * i + 1], BITS)};
+            FRAD_GPTR(v2d, dst + u * U)[i] = v;
         }
     }
     if (chunk == 0)
@@ -479,12 +479,12 @@ __device__ FRAD_NOINLINE void store_pcm_quads(int smem_off, double* __restrict__
             const cx<double> a = buf[phys<double, SH>(zq)], b = buf[phys<double, SH>(M - 1 - zq)];
             row[0][c] = a.x; row[2][c] = a.y; row[3][c] = b.x; row[1][c] = b.y;
         }
-        double2* dst = reinterpret_cast<double2*>(out + (f0 + fl) * (long long)g.N * CC + (long long)zq * 4 * CC);
+        auto dst = FRAD_GPTR(v2d, out + (f0 + fl) * (long long)g.N * CC + (long long)zq * 4 * CC);
         if constexpr (CC == 2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { double2 v; v.x = row[i][0]; v.y = row[i][1]; dst[i] = v; }
+            for (int i = 0; i < 4; ++i) { v2d v = {row[i][0], row[i][1]}; dst[i] = v; }
         } else {
-            double2 v0, v1; v0.x = row[0][0]; v0.y = row[1][0]; v1.x = row[2][0]; v1.y = row[3][0];
+            v2d v0 = {row[0][0], row[1][0]}, v1 = {row[2][0], row[3][0]};
             dst[0] = v0; dst[1] = v1;
         }
     }
@@ -604,11 +604,11 @@ __device__ FRAD_NOINLINE void store_pcm_f64(int smem_off, double* __restrict__ o
             for (int p = threadIdx.x; p < pairs; p += blockDim.x) {
                 const int e = 2 * p;
                 int n = e / C, c = e - n * C;
-                double2 v;
-                v.x = xslot<double, SH>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n);
+                const double v0 = xslot<double, SH>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n);
                 if (++c == C) { c = 0; ++n; }
-                v.y = xslot<double, SH>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n);
-                reinterpret_cast<double2*>(dst)[p] = v;
+                const double v1 = xslot<double, SH>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n);
+                v2d v = {v0, v1};
+                FRAD_GPTR(v2d, dst)[p] = v;
             }
         } else {
             for (int e = threadIdx.x; e < NC; e += blockDim.x) {

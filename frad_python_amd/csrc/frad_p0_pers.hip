@@ -132,7 +132,7 @@ int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const 
         ((g.in_mode == 1) || (g.in_mode == 2 && (8 >> lg) == g.C) || (g.in_mode == 3 && lg >= (g.C == 1 ? 4 : 3)))) {
         // unit-synchronised kernel: one frame per unit of C waves, 8 / C units per block
         const int upb = 8 / g.C;
-        const size_t lds = (size_t)pers_table_bytes<double, PlanA10>() + 64 + 8 * 1024 * 16;
+        const size_t lds = (size_t)pers_table_bytes<double, PlanA10>() + 128 + 8 * 1024 * 16;
         const long long nb = (g.n_frames + upb - 1) / upb, cap = (long long)cu_count() * blocks_per_cu();
         const int grid = (int)(nb < cap ? nb : cap);
         if (lg == 1) go_fwd_unit<1>(tb.blob, g.C, lds, grid, s, pcm, pay, am, g);
@@ -140,6 +140,7 @@ int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const 
         else go_fwd_unit<3>(tb.blob, g.C, lds, grid, s, pcm, pay, am, g);
         return 1;
     }
+    if (am != nullptr && hipMemsetAsync(am, 0, sizeof(double) * (size_t)g.n_frames, s) != hipSuccess) return 0;
     const bool pb = !f32 && plan_b() && tb.blob_b != nullptr && lg <= 2;
     const int team = f32 ? PlanA11::TEAM : pb ? PlanB10::TEAM : PlanA10::TEAM, M = 1 << c.log2m;
     const int cpt = (int)(((long long)g.N << lg) / (16 * team));
@@ -169,7 +170,7 @@ int launch_p0_inv_pers(const FastCfg& c, hipStream_t s, const unsigned char* pay
     if (disabled() || tb.blob == nullptr || c.cg != g.C || c.log2m != 10 || g.C > 2 || g.cc_fast != g.C || g.in_mode != g.C) return 0;
     if (unit_sync() && !plan_b()) {
         const int upb = 8 / g.C;
-        const size_t lds = (size_t)pers_table_bytes<double, PlanA10>() + 64 + 8 * 1024 * 16;
+        const size_t lds = (size_t)pers_table_bytes<double, PlanA10>() + 128 + 8 * 1024 * 16;
         const long long nb = (g.n_frames + upb - 1) / upb, cap = (long long)cu_count() * blocks_per_cu();
         const int grid = (int)(nb < cap ? nb : cap);
         switch (g.bits) {

@@ -389,7 +389,7 @@ __device__ __forceinline__ u64 pack_frame_pairs(const unsigned char* data, unsig
 }
 // out-of-line so that the six storage formats do not count against the transform's registers
 template <typename T, int SH, int CC>
-__device__ FRAD_NOINLINE void pack_frame_pairs_any(int data_off, unsigned char* __restrict__ dst, double* absmax_f, int bits,
+__device__ FRAD_NOINLINE void pack_frame_pairs_any(int data_off, unsigned char* __restrict__ dst, int wmax_off, int bits,
                                                    int le, int utid, int M) {
     FRAD_DYN_SMEM(smem);
     const unsigned char* data = smem + data_off;
@@ -403,7 +403,7 @@ __device__ FRAD_NOINLINE void pack_frame_pairs_any(int data_off, unsigned char* 
         default: mx = pack_frame_pairs<T, 64, SH, CC>(data, dst, le != 0, utid, M); break;
     }
     mx = wave_max_u64(mx);
-    if (absmax_f != nullptr && (threadIdx.x & 63) == 0 && mx != 0) atomicMax(reinterpret_cast<u64*>(absmax_f), mx);
+    if ((threadIdx.x & 63) == 0) reinterpret_cast<u64*>(smem + wmax_off)[threadIdx.x >> 6] = mx;   // per-wave max, combined by the unit
 }
 
 template <typename T, typename PL, int LG, int CC>
@@ -412,7 +412,7 @@ k_p0_fwd_unit(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
               const cx<T>* __restrict__ blob, Geom g) {
     constexpr int LOG2M = PL::LOG2M, M = 1 << LOG2M, N = 2 * M, TEAM = PL::TEAM, SH = PL::SH;
     static_assert(TEAM == 64, "one wave per channel-frame");
-    constexpr int TB = pers_table_bytes<T, PL>(), CTRB = 64;
+    constexpr int TB = pers_table_bytes<T, PL>(), CTRB = 128;    // 16 barrier words + 8 per-wave |X| maxima
     constexpr int CPT = (N << LG) / (16 * TEAM), EPC = 16 >> LG;
     constexpr int UTH = CC * 64, UPB = 8 / CC;               // threads per unit, units per block
     FRAD_DYN_SMEM(smem);
@@ -524,8 +524,14 @@ k_p0_fwd_unit(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
 #pragma unroll
             for (int j = 0; j < 4; ++j) FRAD_OPAQUE(pf[i][j]);    // retire the prefetch before the store burst
         unit_barrier<CC>(ctr, epoch);
-        pack_frame_pairs_any<T, SH, CC>(data_off, payload + f * g.payload_stride, absmax ? absmax + f : nullptr, g.bits, g.le, utid, M);
+        pack_frame_pairs_any<T, SH, CC>(data_off, payload + f * g.payload_stride, TB + 64, g.bits, g.le, utid, M);
         unit_barrier<CC>(ctr, epoch);
+        if (absmax != nullptr && utid0 == 0) {                // plain store: no atomics, no memset before the launch
+            const u64* wm = reinterpret_cast<const u64*>(smem + TB + 64) + unit * CC;
+            u64 m = wm[0];
+            if constexpr (CC == 2) m = wm[1] > m ? wm[1] : m;
+            *FRAD_GPTR(u64, absmax + f) = m;
+        }
         f = next;
     }
 }
@@ -543,12 +549,12 @@ __device__ FRAD_NOINLINE void store_frame_quads(int data_off, double* __restrict
             const cx<double> a = buf[phys<double, SH>(zq)], b = buf[phys<double, SH>(M - 1 - zq)];
             row[0][c] = a.x; row[2][c] = a.y; row[3][c] = b.x; row[1][c] = b.y;
         }
-        double2* dst = reinterpret_cast<double2*>(dstf + (long long)zq * 4 * CC);
+        auto dst = FRAD_GPTR(v2d, dstf + (long long)zq * 4 * CC);
         if constexpr (CC == 2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { double2 v; v.x = row[i][0]; v.y = row[i][1]; dst[i] = v; }
+            for (int i = 0; i < 4; ++i) { v2d v = {row[i][0], row[i][1]}; dst[i] = v; }
         } else {
-            double2 v0, v1; v0.x = row[0][0]; v0.y = row[1][0]; v1.x = row[2][0]; v1.y = row[3][0];
+            v2d v0 = {row[0][0], row[1][0]}, v1 = {row[2][0], row[3][0]};
             dst[0] = v0; dst[1] = v1;
         }
     }
@@ -559,7 +565,7 @@ __global__ void __launch_bounds__(512, 2)
 k_p0_inv_unit(const unsigned char* __restrict__ payload, double* __restrict__ out, const cx<double>* __restrict__ blob, Geom g) {
     constexpr int LOG2M = PL::LOG2M, M = 1 << LOG2M, N = 2 * M, TEAM = PL::TEAM, SH = PL::SH;
     static_assert(TEAM == 64, "one wave per channel-frame");
-    constexpr int TB = pers_table_bytes<double, PL>(), CTRB = 64;
+    constexpr int TB = pers_table_bytes<double, PL>(), CTRB = 128;
     constexpr int U = unit_values(BITS), UB = unit_bytes(BITS);
     constexpr int V = U > 2 * CC ? U : 2 * CC, KB = V / CC, UPV = V / U;
     constexpr int TPT = N / (V * TEAM);

@@ -15,6 +15,11 @@
 #define FRAD_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 // make a lane value opaque to the optimiser (used to stop loop-invariant code motion from parking
 // hundreds of per-lane LDS addresses in VGPRs across a persistent loop)
+// a pointer that went through a real (noinline) call is "generic" to the compiler and gets FLAT
+// instructions, which also count on lgkmcnt -- an LDS-only wait would then wait for global stores.
+// These casts put device-memory pointers back into the global address space.
+#define FRAD_GPTR(T, p) ((__attribute__((address_space(1))) T*)(p))
+#define FRAD_GCPTR(T, p) ((const __attribute__((address_space(1))) T*)(p))
 #define FRAD_OPAQUE(x) asm volatile("" : "+v"(x))
 // workgroup barrier that only waits for this wave's LDS traffic: __syncthreads() also drains vmcnt,
 // i.e. every global load and store in flight, which is exactly what a pipelined kernel must not do

@@ -68,6 +68,8 @@ template <typename F> void launch(dim3 grid, dim3 block, size_t lds, F&& body) {
 #define gridDim emu::g_dim
 #define FRAD_DYN_SMEM(name) unsigned char* name = emu::smem_base()
 #define FRAD_OPAQUE(x) asm volatile("" : "+r"(x))
+#define FRAD_GPTR(T, p) ((T*)(p))
+#define FRAD_GCPTR(T, p) ((const T*)(p))
 #define FRAD_LDS_BARRIER() __syncthreads()
 
 inline void __syncthreads() { emu::blk->bar.arrive_and_wait(); }
