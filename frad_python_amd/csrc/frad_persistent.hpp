@@ -536,26 +536,29 @@ k_p0_fwd_unit(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
     }
 }
 
+// Decode epilogue of a unit: one interleaved output row (or row pair for mono) per lane, so that every
+// store instruction of a wave writes 64 x 16 contiguous bytes.  Row n of channel c is component
+// (n&3 in {1,2}) of slot z[n>>2] (n even) or z[M-1-(n>>2)] (n odd) -- Makhoul's permutation undone on the
+// read side with conflict-free 8-byte LDS reads.
 template <int SH, int CC>
-__device__ FRAD_NOINLINE void store_frame_quads(int data_off, double* __restrict__ dstf, int utid, int M) {
+__device__ FRAD_NOINLINE void store_frame_rows(int data_off, double* __restrict__ dstf, int utid, int M) {
     FRAD_DYN_SMEM(smem);
-    const unsigned char* data = smem + data_off;
-    const int quads = M / 2, uth = CC * 64;                   // N / 4
-    for (int zq = utid; zq < quads; zq += uth) {
-        double row[4][CC];
-#pragma unroll
-        for (int c = 0; c < CC; ++c) {
-            const cx<double>* buf = reinterpret_cast<const cx<double>*>(data) + (long long)c * M;
-            const cx<double> a = buf[phys<double, SH>(zq)], b = buf[phys<double, SH>(M - 1 - zq)];
-            row[0][c] = a.x; row[2][c] = a.y; row[3][c] = b.x; row[1][c] = b.y;
+    const double* data = reinterpret_cast<const double*>(smem + data_off);
+    const int N = 2 * M, uth = CC * 64;
+    auto sample = [&](int c, int n) -> double {
+        const int q = n >> 2, r = n & 3;
+        const int slot = (r & 1) ? (M - 1 - q) : q;
+        return data[((long long)c * M + phys<double, SH>(slot)) * 2 + ((r == 1) | (r == 2))];
+    };
+    if constexpr (CC == 2) {
+        for (int n = utid; n < N; n += uth) {
+            v2d v = {sample(0, n), sample(1, n)};
+            FRAD_GPTR(v2d, dstf)[n] = v;
         }
-        auto dst = FRAD_GPTR(v2d, dstf + (long long)zq * 4 * CC);
-        if constexpr (CC == 2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { v2d v = {row[i][0], row[i][1]}; dst[i] = v; }
-        } else {
-            v2d v0 = {row[0][0], row[1][0]}, v1 = {row[2][0], row[3][0]};
-            dst[0] = v0; dst[1] = v1;
+    } else {
+        for (int p = utid; p < N / 2; p += uth) {
+            v2d v = {sample(0, 2 * p), sample(0, 2 * p + 1)};
+            FRAD_GPTR(v2d, dstf)[p] = v;
         }
     }
 }
@@ -639,7 +642,7 @@ k_p0_inv_unit(const unsigned char* __restrict__ payload, double* __restrict__ ou
 #pragma unroll
                 for (int j = 0; j < UB / 4; ++j) FRAD_OPAQUE(pf[i][w][j]);
         unit_barrier<CC>(ctr, epoch);
-        store_frame_quads<SH, CC>(data_off, out + f * (long long)N * CC, utid, M);
+        store_frame_rows<SH, CC>(data_off, out + f * (long long)N * CC, utid, M);
         unit_barrier<CC>(ctr, epoch);
         f = next;
     }
