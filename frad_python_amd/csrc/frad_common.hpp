@@ -91,7 +91,9 @@ __device__ __forceinline__ T cvt_pcm(u64 raw, int code, bool raw_be_ints) {
 // The same conversion with the format known at compile time (CODE = FRAD_PCM_* value, RAW = the
 // big-endian-integer quirk): branch-free, a handful of VALU ops per element.  Kernels pick the
 // instantiation once per stage through dispatch_pcm() instead of branching per element.
-template <typename T, int CODE, bool RAW>
+// NOSCALE: leave signed integers un-normalised -- the caller folds the exact factor 2^-(w-1) into a later
+// multiplication (see pcm_deferred_scale), which saves one float64 op per sample.
+template <typename T, int CODE, bool RAW, bool NOSCALE = false>
 __device__ __forceinline__ T cvt_pcm_c(u64 raw) {
     constexpr int kind = CODE >> 3, lg = (CODE >> 1) & 3, be = CODE & 1;
     if constexpr (be) {
@@ -114,10 +116,17 @@ __device__ __forceinline__ T cvt_pcm_c(u64 raw) {
             else v = (double)raw;
         }
         if constexpr (be && RAW) return (T)v;
+        if constexpr (NOSCALE && kind == 1) return (T)v;
         v = v * u2d((u64)(1023 - (w - 1)) << 52);
         if constexpr (kind == 0) v = v - 1.0;
         return (T)v;
     }
+}
+// the factor cvt_pcm_c<.., NOSCALE = true> leaves out for this (dtype, raw_be); 1 when it left nothing out
+__device__ __forceinline__ double pcm_deferred_scale(int dtype, int raw_be) {
+    const int kind = dtype >> 3, lg = (dtype >> 1) & 3, be = dtype & 1;
+    if (kind != 1 || (be && raw_be)) return 1.0;
+    return u2d((u64)(1023 - ((8 << lg) - 1)) << 52);
 }
 
 template <int V> struct ic { static constexpr int value = V; };

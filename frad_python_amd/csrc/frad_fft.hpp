@@ -36,6 +36,13 @@ template <typename T, int SH> __device__ __forceinline__ int phys(int i) {
     if constexpr (SH < 0) return i;
     else return i ^ ((i >> SH) & (sizeof(cx<T>) == 16 ? 7 : 15));
 }
+// phys(t + c) for c a multiple of 16: the swizzle only touches the low 3-4 bits, which c leaves alone, so
+// the constant stays outside the XOR and folds into the ds_read/ds_write immediate offset; the XOR term
+// takes two values at most over a pass, i.e. two VALU ops instead of four per access.
+template <typename T, int SH> __device__ __forceinline__ int phys_tc(int t, int c) {
+    if constexpr (SH < 0) return t + c;
+    else return c + (t ^ (((t >> SH) + (c >> SH)) & (sizeof(cx<T>) == 16 ? 7 : 15)));
+}
 __host__ __device__ constexpr int padded_slots(int m) { return m; }
 
 // constants (correctly rounded)
@@ -185,9 +192,11 @@ __device__ __forceinline__ void fft_pass_lt(cx<T>* buf, int t, const cx<T>* ptab
     cx<T> v[NB][R];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const int b = t + nb * TEAM;
 #pragma unroll
-        for (int j = 0; j < R; ++j) v[nb][j] = buf[phys<T, SH>(b + j * (M / R))];
+        for (int j = 0; j < R; ++j) {
+            if constexpr (TEAM % 16 == 0 && (M / R) % 16 == 0) v[nb][j] = buf[phys_tc<T, SH>(t, nb * TEAM + j * (M / R))];
+            else v[nb][j] = buf[phys<T, SH>(t + nb * TEAM + j * (M / R))];
+        }
     }
     team_sync<TEAM, true>();
 #pragma unroll
@@ -206,7 +215,10 @@ __device__ __forceinline__ void fft_pass_lt(cx<T>* buf, int t, const cx<T>* ptab
         dft<R, INV>(v[nb]);
         const int base = (b - k) * R + k;
 #pragma unroll
-        for (int j = 0; j < R; ++j) buf[phys<T, SH>(base + j * NS)] = v[nb][j];
+        for (int j = 0; j < R; ++j) {
+            if constexpr (NS * R == M && TEAM % 16 == 0 && NS % 16 == 0) buf[phys_tc<T, SH>(t, nb * TEAM + j * NS)] = v[nb][j];   // last pass: b + j*NS
+            else buf[phys<T, SH>(base + j * NS)] = v[nb][j];
+        }
     }
     team_sync<TEAM, true>();
 }
@@ -267,19 +279,21 @@ __device__ __forceinline__ int makhoul(int n, int N) { return (n & 1) ? N - 1 - 
 //
 // forward: Z (FFT of the packed sequence) -> X[k] = (1/N) sum x[n] cos(pi k (2n+1) / 2N), in place.
 template <typename T, int LOG2M, int PS = 2, int TEAM = Plan<LOG2M>::TEAM, int SH = Plan<LOG2M>::SH, bool LDSONLY = false>
-__device__ __forceinline__ void dct_post(cx<T>* buf, int t, const cx<T>* __restrict__ post) {
+__device__ __forceinline__ void dct_post(cx<T>* buf, int t, const cx<T>* __restrict__ post, T extra = (T)1) {
     constexpr int GOFF = PS == 2 ? 1 : (1 << LOG2M) / 2 + 1;   // where g_k lives relative to w_k
     constexpr int M = 1 << LOG2M, N = 2 * M;
     constexpr int PP = (M / 2) / TEAM;         // pairs per lane (pair M/2 goes to lane 0 on top)
-    constexpr T sc = (T)1 / (T)(2 * N);
-    constexpr T sc2 = K<T>::s2 / (T)(2 * N);
+    // `extra` is an exact power of two (a deferred PCM normalisation): scaling by it commutes with rounding
+    const T sc = ((T)1 / (T)(2 * N)) * extra;
+    const T sc2 = (K<T>::s2 / (T)(2 * N)) * extra;
     cx<T> S[PP + 1], D[PP + 1];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i <= PP; ++i) {
         const int k = (i < PP) ? t + i * TEAM : M / 2;
         if (i == PP && t != 0) continue;
-        const cx<T> zk = buf[phys<T, SH>(k)], zp = conj(buf[phys<T, SH>((M - k) & (M - 1))]);
+        const cx<T> zk = (i < PP && TEAM % 16 == 0) ? buf[phys_tc<T, SH>(t, i * TEAM)] : buf[phys<T, SH>(k)];
+        const cx<T> zp = conj(buf[phys<T, SH>((M - k) & (M - 1))]);
         const cx<T> p = cmul(zk + zp, post[PS * k]), q = cmul(zk - zp, post[PS * k + GOFF]);
         S[i] = p + q; D[i] = p - q;
     }

@@ -359,7 +359,8 @@ __device__ __forceinline__ u64 pack_frame_pairs(const unsigned char* data, unsig
     constexpr int U = unit_values(BITS), UB = unit_bytes(BITS);
     constexpr int V = U > 2 * CC ? U : 2 * CC, KB = V / CC;
     const int tasks = (2 * M * CC) / V, uth = CC * 64;
-    u64 mx = 0;
+    double fm = 0.0;
+    bool nan = false;
     for (int u = utid; u < tasks; u += uth) {
         u64 codes[V];
         const int s0 = (u * KB) >> 1;
@@ -369,8 +370,9 @@ __device__ __forceinline__ u64 pack_frame_pairs(const unsigned char* data, unsig
 #pragma unroll
             for (int kk = 0; kk < KB / 2; ++kk) {
                 const cx<T> z = buf[phys<T, SH>(s0 + kk)];
-                const u64 a = abs_bits((double)z.x), b = abs_bits((double)z.y);
-                mx = a > mx ? a : mx; mx = b > mx ? b : mx;
+                // |x| max as two float ops; NaN is tracked apart (fmax drops it) and re-imposed at the end
+                fm = fmax(fm, fmax(fabs((double)z.x), fabs((double)z.y)));
+                nan |= (z.x != z.x) | (z.y != z.y);
                 codes[(2 * kk) * CC + c] = storage_code<T>(z.x, BITS);
                 codes[(2 * kk + 1) * CC + c] = storage_code<T>(z.y, BITS);
             }
@@ -385,7 +387,7 @@ __device__ __forceinline__ u64 pack_frame_pairs(const unsigned char* data, unsig
             store_words<UB / 4>(dst + ((long long)u * (V / U) + w) * UB, out);
         }
     }
-    return mx;
+    return nan ? 0x7ff8000000000000ULL : d2u(fm);             // np.max(np.abs(.)) propagates NaN
 }
 // out-of-line so that the six storage formats do not count against the transform's registers
 template <typename T, int SH, int CC>
@@ -462,7 +464,7 @@ k_p0_fwd_unit(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
                     for (int e = 0; e < EPC; ++e) {
                         T v[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = cvt_pcm_c<T, CODE, RAW>(word_elem<LG>(pf[4 * k + i], e));
+                        for (int i = 0; i < 4; ++i) v[i] = cvt_pcm_c<T, CODE, RAW, true>(word_elem<LG>(pf[4 * k + i], e));
                         put(sl * EPC + e, zq, v[0], v[1], v[2], v[3]);
                     }
                 }
@@ -478,7 +480,7 @@ k_p0_fwd_unit(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int idx = i * CC + c;
-                            v[i] = cvt_pcm_c<T, CODE, RAW>(word_elem<LG>(pf[2 * k + idx / EPC], idx % EPC));
+                            v[i] = cvt_pcm_c<T, CODE, RAW, true>(word_elem<LG>(pf[2 * k + idx / EPC], idx % EPC));
                         }
                         put(c, zq, v[0], v[1], v[2], v[3]);
                     }
@@ -496,7 +498,7 @@ k_p0_fwd_unit(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
                         for (int c = 0; c < CC; ++c) {
                             T v[4];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = cvt_pcm_c<T, CODE, RAW>(word_elem<LG>(pf[i], (gi * 4 + r) * CC + c));
+                            for (int r = 0; r < 4; ++r) v[r] = cvt_pcm_c<T, CODE, RAW, true>(word_elem<LG>(pf[i], (gi * 4 + r) * CC + c));
                             put(c, ch * GPC + gi, v[0], v[1], v[2], v[3]);
                         }
                 }
@@ -504,6 +506,7 @@ k_p0_fwd_unit(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         }
     };
 
+    const T deferred = (T)pcm_deferred_scale(g.dtype, g.raw_be);   // signed PCM stays un-normalised until the DCT step
     const long long stride = (long long)gridDim.x * UPB;
     long long f = (long long)blockIdx.x * UPB + unit;
     if (f < g.n_frames) prefetch(f);
@@ -518,7 +521,7 @@ k_p0_fwd_unit(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         FRAD_OPAQUE(t); FRAD_OPAQUE(co);
         cx<T>* buf = reinterpret_cast<cx<T>*>(data) + co;
         fft_team_lt<T, PL, false>(buf, t, ltab);
-        dct_post<T, LOG2M, 1, TEAM, SH, true>(buf, t, lpost);
+        dct_post<T, LOG2M, 1, TEAM, SH, true>(buf, t, lpost, deferred);
 #pragma unroll
         for (int i = 0; i < CPT; ++i)
 #pragma unroll
