@@ -57,6 +57,62 @@ __device__ __forceinline__ void fft_team_lt(cx<T>* buf, int t, const cx<T>* ltab
     if constexpr (PL::R4 != 0) fft_pass_lt<T, M, TEAM, PL::R4, L::NS4, INV, SH>(buf, t, ltab + L::OFF4);
 }
 
+// Last radix-4 pass of plan A (M = 1024) fused with the DCT pair step.  A lane takes the four
+// butterflies k0 in {l, 64+l, 192-l, 256-l} (lane 0: {0, 64, 192, 128}); their outputs Z[k0 + 256 j] then
+// contain both members of every pair (k, M-k) the DCT step needs, so that step runs on registers and the
+// pass's own LDS write + read-back (and one team sync) disappear.  Writes X[0..N) over the buffer.
+template <typename T, typename PL>
+__device__ __forceinline__ void fft_last_pass_dct(cx<T>* buf, int l, const cx<T>* ltab, const cx<T>* lpost, T extra) {
+    constexpr int M = 1 << PL::LOG2M, N = 2 * M, SH = PL::SH, TEAM = PL::TEAM;
+    static_assert(M == 1024 && TEAM == 64 && PL::R3 == 4 && PL::R4 == 0, "plan A, N = 2048");
+    using L = PersLayout<PL>;
+    const cx<T>* tw3 = ltab + L::OFF3;
+    constexpr int GOFF = M / 2 + 1;
+    const bool lane0 = (l == 0);
+    const int k0[4] = {l, 64 + l, 192 - l, lane0 ? 128 : 256 - l};
+    cx<T> z[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[b][j] = buf[phys<T, SH>(k0[b] + 256 * j)];
+    }
+    team_sync<TEAM, true>();                               // every lane has its inputs: the buffer may be overwritten
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int nb = k0[b] >> 6, kk = k0[b] & 63;
+#pragma unroll
+        for (int j = 1; j < 4; ++j) z[b][j] = cmul(z[b][j], tw3[(nb * 3 + (j - 1)) * 64 + kk]);
+        dft<4, false>(z[b]);
+    }
+    const T sc = ((T)1 / (T)(2 * N)) * extra, sc2 = (K<T>::s2 / (T)(2 * N)) * extra;
+    auto pair = [&](int k, cx<T> zk, cx<T> zm) {            // zk = Z[k], zm = Z[M - k]
+        const cx<T> zp = conj(zm);
+        const cx<T> p = cmul(zk + zp, lpost[k]), q = cmul(zk - zp, lpost[k + GOFF]);
+        const cx<T> S = p + q, D = p - q;
+        real_slot<T, SH>(buf, k) = S.x * sc;
+        if (k > 0) real_slot<T, SH>(buf, N - k) = -S.y * sc;
+        if (k < M / 2) {
+            real_slot<T, SH>(buf, M - k) = (D.x - D.y) * sc2;
+            if (k > 0) real_slot<T, SH>(buf, M + k) = (D.x + D.y) * sc2;
+        }
+    };
+    auto sel = [&](cx<T> a, cx<T> b) { return cx<T>{lane0 ? a.x : b.x, lane0 ? a.y : b.y}; };
+    // pairs inside {64+l, 192-l}: (64 + l + 256 j) with (192 - l + 256 (3 - j)); the smaller index leads
+    pair(64 + l, z[1][0], z[2][3]);
+    pair(320 + l, z[1][1], z[2][2]);
+    pair(448 - l, z[2][1], z[1][2]);
+    pair(192 - l, z[2][0], z[1][3]);
+    // pairs inside {l, 256-l}; lane 0 holds {0, 128} instead and pairs them with themselves:
+    //   lane l >= 1: (l, 1024-l) (256+l, 768-l) (512-l, 512+l) (256-l, 768+l)
+    //   lane 0     : (0, 0)      (256, 768)     (512, 512)     (128, 896)      + the extra pair (384, 640)
+    pair(l, z[0][0], sel(z[0][0], z[3][3]));
+    pair(256 + l, z[0][1], sel(z[0][3], z[3][2]));
+    pair(512 - l, sel(z[0][2], z[3][1]), z[0][2]);
+    pair(lane0 ? 128 : 256 - l, z[3][0], sel(z[3][3], z[0][3]));
+    if (lane0) pair(384, z[3][1], z[3][2]);
+    team_sync<TEAM, true>();
+}
+
 // ---------------------------------------------------------------------------------------------
 // encode.  grid = min(groups, CUs); block = teams * TEAM threads, teams = fpb * C (<= 8).
 // Per iteration a thread stages CPT = N * itemsize / (16 * TEAM) 16-byte chunks of PCM.
@@ -520,8 +576,9 @@ k_p0_fwd_unit(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         int t = utid & 63, co = (utid >> 6) * M;
         FRAD_OPAQUE(t); FRAD_OPAQUE(co);
         cx<T>* buf = reinterpret_cast<cx<T>*>(data) + co;
-        fft_team_lt<T, PL, false>(buf, t, ltab);
-        dct_post<T, LOG2M, 1, TEAM, SH, true>(buf, t, lpost, deferred);
+        fft_pass_lt<T, M, TEAM, PL::R1, 1, false, SH>(buf, t, ltab);
+        fft_pass_lt<T, M, TEAM, PL::R2, PersLayout<PL>::NS2, false, SH>(buf, t, ltab + PersLayout<PL>::OFF2);
+        fft_last_pass_dct<T, PL>(buf, t, ltab, lpost, deferred);
 #pragma unroll
         for (int i = 0; i < CPT; ++i)
 #pragma unroll

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Secondary measurements for DESIGN.md (not the headline bench): kernel-only HIP-event timings of the other
+BASELINE configurations -- profile 4 pack/unpack at the cfg-2 size, cfg 4 (192 kHz 7.1 f32, N=4096), cfg 5
+(profile 1 quantiser, N=2048 hop 1920) -- as algorithmic GB/s and fraction of the 8 TB/s HBM peak."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from frad_python_amd import core  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, reps=20, warm=5):
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in ev]))
+
+
+def line(name, nbytes, ms, samples):
+    gbs = nbytes / ms / 1e6
+    return {"case": name, "ms": round(ms, 4), "GB/s": round(gbs, 1), "hbm_frac": round(gbs / 8000, 4),
+            "Gsamples/s": round(samples / ms / 1e6, 2)}
+
+
+out = []
+g = torch.Generator(device=dev).manual_seed(1)
+# profile 4 (pure cast + pack), cfg-2 sized, s16 -> 32-bit and 24-bit
+F, N, C = 14062, 2048, 2
+pcm = (torch.randn((F * N, C), generator=g, device=dev) * 8000).clamp(-32768, 32767).to(torch.int16)
+S = F * N * C
+for bits in (32, 24, 16):
+    enc = core.analogue_batch(4, pcm, "s16le", F, N, C, bits, check_overflow=False)
+    o = torch.empty((F, N, C), dtype=torch.float64, device=dev)
+    out.append(line(f"p4 encode s16->b{bits}", S * (2 + bits / 8), timeit(lambda: core.analogue_batch(4, pcm, "s16le", F, N, C, bits, check_overflow=False, out=enc.payload, absmax=enc.absmax)), S))
+    out.append(line(f"p4 decode b{bits}->f64", S * (bits / 8 + 8), timeit(lambda: core.digital_batch(4, enc.payload, F, N, C, bits, out=o)), S))
+# cfg 4: 60 s of 192 kHz 8-channel f32, N = 4096, 32 bit
+F, N, C = 2812, 4096, 8
+pcm4 = (torch.rand((F * N, C), generator=g, device=dev) * 1.8 - 0.9).to(torch.float32)
+S = F * N * C
+enc = core.analogue_batch(0, pcm4, "f32le", F, N, C, 32, check_overflow=False)
+o = torch.empty((F, N, C), dtype=torch.float64, device=dev)
+out.append(line("cfg4 p0 encode f32 8ch N=4096 (f32 compute)", S * 8, timeit(lambda: core.analogue_batch(0, pcm4, "f32le", F, N, C, 32, check_overflow=False, out=enc.payload, absmax=enc.absmax)), S))
+out.append(line("cfg4 p0 decode (f64, channel-group kernel)", S * 12, timeit(lambda: core.digital_batch(0, enc.payload, F, N, C, 32, out=o)), S))
+# cfg 5: 60 s stereo s16, profile 1, N = 2048, hop 1920, loss level 20
+N, C, hop = 2048, 2, 1920
+n = 60 * 48000
+F = (n - N) // hop + 1
+pcm5 = (torch.randn((n, C), generator=g, device=dev) * 3000).clamp(-32768, 32767).to(torch.int16)
+loss = 1.25 ** 20 / 19 + 0.5
+q, tq = core.p1_analogue_batch(pcm5, "s16le", F, N, C, 16, 48000, loss, frame_stride=hop)
+out.append(line("cfg5 p1 quantise (K7)", F * (N * C * 2 + N * C * 4 + 27 * C * 4), timeit(lambda: core.p1_analogue_batch(pcm5, "s16le", F, N, C, 16, 48000, loss, frame_stride=hop)), F * hop * C))
+out.append(line("cfg5 p1 dequantise+IDCT (K8)", F * (N * C * 4 + 27 * C * 4 + N * C * 8), timeit(lambda: core.p1_digital_batch(q, tq, N, C, 16, 48000)), F * hop * C))
+dec = core.p1_digital_batch(q, tq, N, C, 16, 48000)
+out.append(line("cfg5 overlap-add", F * (N * C * 8 + hop * C * 8), timeit(lambda: core.p1_overlap_add(dec, 16)), F * hop * C))
+for o_ in out:
+    print(json.dumps(o_))
