@@ -661,6 +661,7 @@ __device__ FRAD_NOINLINE void pack_out_group(int smem_off, unsigned char* __rest
         }
     } else {
         const int nb = bits >> 3;
+        const bool sized = (nb == 2 || nb == 4 || nb == 8) && (reinterpret_cast<uintptr_t>(dst) % nb == 0);
         for (int q = threadIdx.x; q < N * cgn; q += blockDim.x) {
             const int k = q / cgn, j = q - k * cgn;
             const T v = xslot<T, SH>(smem, j, slots, k);
@@ -668,7 +669,13 @@ __device__ FRAD_NOINLINE void pack_out_group(int smem_off, unsigned char* __rest
             mx = a > mx ? a : mx;
             const u64 code = storage_code<T>(v, bits);
             const long long o = ((long long)k * C + c0 + j) * nb;
-            for (int b = 0; b < nb; ++b) dst[o + b] = (unsigned char)code_byte(code, bits, le, b);
+            if (sized) {                                      // one element-sized store
+                if (nb == 4) *FRAD_GPTR(uint32_t, dst + o) = le ? (uint32_t)code : bswap32((uint32_t)code);
+                else if (nb == 8) *FRAD_GPTR(u64, dst + o) = le ? code : bswap64(code);
+                else *FRAD_GPTR(unsigned short, dst + o) = (unsigned short)(le ? (uint32_t)code : bswap16((uint32_t)code));
+            } else {
+                for (int b = 0; b < nb; ++b) dst[o + b] = (unsigned char)code_byte(code, bits, le, b);
+            }
         }
     }
     block_absmax_commit(mx, absmax, f);
@@ -682,9 +689,19 @@ __device__ FRAD_NOINLINE void unpack_in_group(const unsigned char* __restrict__ 
     const int N = g.N, C = g.C;
     const bool le = g.le && (g.bits % 8 == 0);
     const unsigned char* src = payload + f * g.payload_stride;
+    const bool sized = (g.bits == 16 || g.bits == 32 || g.bits == 64) && (reinterpret_cast<uintptr_t>(src) % (g.bits / 8) == 0);
     for (int q = threadIdx.x; q < N * cgn; q += blockDim.x) {
         const int k = q / cgn, j = q - k * cgn;
-        xslot<double, SH>(smem, j, slots, k) = code_to_f64(code_from_bytes(src, (long long)k * C + c0 + j, g.bits, le), g.bits);
+        const long long idx = (long long)k * C + c0 + j;
+        u64 code;
+        if (sized) {                                          // one element-sized load instead of byte loads
+            const int lgb = g.bits == 16 ? 1 : g.bits == 32 ? 2 : 3;
+            code = load_raw(src + (idx << lgb), lgb);
+            if (!le) code = lgb == 1 ? bswap16((uint32_t)code) : lgb == 2 ? bswap32((uint32_t)code) : bswap64(code);
+        } else {
+            code = code_from_bytes(src, idx, g.bits, le);
+        }
+        xslot<double, SH>(smem, j, slots, k) = code_to_f64(code, g.bits);
     }
 }
 

@@ -118,65 +118,79 @@ class Decoder:
             out.append(frame)
         return out
 
-    # ------------------------------------------------------------------ the reference's process() loop, batched
+    # ------------------------------------------------------------------ stream parsing
+    def _lock_on_signature(self) -> bool:
+        """Position the parser on the next FRM_SIGN (decoder.py:82-90): True once a header has begun."""
+        sign = common.FRM_SIGN
+        if self.asfh.buffer[:len(sign)] == sign:
+            return True
+        at = self.buffer.find(sign)
+        if at < 0:
+            self.buffer = self.buffer[-(len(sign) - 1):]        # keep a possible split signature
+            return False
+        self.asfh.buffer = sign
+        self.buffer = self.buffer[at + len(sign):]
+        return True
+
+    def _take_frame(self, stream_was_empty: bool):
+        """Cut the payload of the header just completed; None while it is still arriving."""
+        need = self.asfh.frmbytes
+        self.broken_frame = False
+        if len(self.buffer) < need:
+            self.broken_frame = stream_was_empty                # process(b'') marks a truncated frame (decoder.py:58-60)
+            return None
+        frad, self.buffer = self.buffer[:need], self.buffer[need:]
+        a = self.asfh
+        if a.profile not in (0, 1, 4):
+            raise NotImplementedError(f"profile {a.profile} is not built (upstream: in development)")
+        if a.ecc:
+            frad = _strip_ecc(frad, a.ecc_dsize, a.ecc_codesize)
+        key = (a.profile, a.fsize, a.channels, a.bit_depth_index, a.endian, a.srate, a.overlap_ratio)
+        a.clear()
+        return key, frad
+
     def process(self, stream: bytes) -> DecodeResult:
+        """Parse as the reference does (decoder.py:51-108) but decode runs of like frames in one launch each."""
         self.buffer += stream
-        ret_pcm, frames = [], 0
+        pieces, frames = [], 0
         run_key, run = None, []
 
         def close_run():
             nonlocal run_key, run
             if run:
-                ret_pcm.extend(self._decode_run(run_key, run))
+                pieces.extend(self._decode_run(run_key, run))
             run_key, run = None, []
 
         while True:
             if self.asfh.all_set:
-                self.broken_frame = False
-                if len(self.buffer) < self.asfh.frmbytes:
-                    if len(stream) == 0:
-                        self.broken_frame = True
+                got = self._take_frame(len(stream) == 0)
+                if got is None:
                     break
-                frad, self.buffer = self.buffer[:self.asfh.frmbytes], self.buffer[self.asfh.frmbytes:]
-                a = self.asfh
-                if a.ecc:
-                    frad = _strip_ecc(frad, a.ecc_dsize, a.ecc_codesize)
-                key = (a.profile, a.fsize, a.channels, a.bit_depth_index, a.endian, a.srate, a.overlap_ratio)
-                if a.profile not in (0, 1, 4):
-                    raise NotImplementedError(f"profile {a.profile} is not built (upstream: in development)")
-                if key != run_key or (run and len(frad) != len(run[0]) and a.profile != 1):
+                key, frad = got
+                if key != run_key or (key[0] != 1 and run and len(frad) != len(run[0])):
                     close_run()
                     run_key = key
                 run.append(frad)
                 frames += 1
-                self.asfh.clear()
-            else:
-                if not self.asfh.buffer[:len(common.FRM_SIGN)] == common.FRM_SIGN:
-                    i = self.buffer.find(common.FRM_SIGN)
-                    if i != -1:
-                        self.buffer = self.buffer[i:]
-                        self.asfh.buffer = self.buffer[:len(common.FRM_SIGN)]
-                        self.buffer = self.buffer[len(common.FRM_SIGN):]
-                    else:
-                        self.buffer = self.buffer[-len(common.FRM_SIGN) + 1:]
-                        break
-                header_result, self.buffer = self.asfh.read(self.buffer)
-                if header_result == "Complete":
-                    if not self.asfh.criteq(self.info):
-                        srate, chnl = self.info.srate, self.info.channels
-                        self.info = self.asfh
-                        if srate or chnl:
-                            close_run()
-                            ret_pcm.append(self.flush().pcm)
-                            return DecodeResult(ret_pcm, srate, frames, True)
-                elif header_result == "ForceFlush":
+                continue
+            if not self._lock_on_signature():
+                break
+            state, self.buffer = self.asfh.read(self.buffer)
+            if state == "Incomplete":
+                break
+            if state == "ForceFlush":
+                close_run()
+                pieces.append(self.flush().pcm)
+                break
+            if not self.asfh.criteq(self.info):                 # channel count or sample rate changed
+                previous = (self.info.srate, self.info.channels)
+                self.info = self.asfh
+                if any(previous):
                     close_run()
-                    ret_pcm.append(self.flush().pcm)
-                    break
-                else:
-                    break
+                    pieces.append(self.flush().pcm)
+                    return DecodeResult(pieces, previous[0], frames, True)
         close_run()
-        return DecodeResult(ret_pcm, self.asfh.srate, frames, False)
+        return DecodeResult(pieces, self.asfh.srate, frames, False)
 
     def flush(self) -> DecodeResult:
         ret = self.overlap_fragment

@@ -1,9 +1,15 @@
-"""Audio Stream Frame Header -- host framing (mirror of src/libfrad/tools/asfh.py of the reference).
+"""Audio Stream Frame Header (ASFH) -- host framing of the FrAD stream.
 
-Layout (big-endian): FRM_SIGN(4) len(4) pfb(1) then
-  lossless profiles: channels-1 (1) ecc dsize,codesize (2) srate (4) zero (8) fsize (4) crc32 (4) = 32 bytes
-  compact profiles : css (2) overlap-1 (1) [ecc dsize,codesize (2) crc16 (2)]                    = 12 / 16 bytes
-pfb = profile<<5 | ecc<<4 | little_endian<<3 | depth index; css = (ch-1)<<10 | srate idx<<6 | fsize idx<<1 | flush.
+Byte-compatible with the reference's `ASFH` (src/libfrad/tools/asfh.py) and same public surface
+(`write`, `read` -> 'Complete' | 'ForceFlush' | 'Incomplete', `force_flush`, `clear`, `criteq`, the public
+fields), because Encoder/Decoder and their callers use it as the frame descriptor.  Layout, big-endian:
+
+    0  FRM_SIGN(4) | 4 payload length(4) | 8 pfb(1) = profile<<5 | ecc<<4 | little_endian<<3 | depth index
+    lossless profiles (0, 4), 32 bytes:  9 channels-1 | 10 ecc dsize | 11 ecc codesize | 12 srate(4) | 16 zero(8)
+                                         | 24 fsize(4) | 28 crc32(payload)(4)
+    compact profiles (1, 2), 12 bytes :  9 css(2) = (channels-1)<<10 | srate idx<<6 | fsize idx<<1 | flush
+                                         | 11 overlap_ratio-1 | with ECC, 16 bytes: 12 dsize | 13 codesize | 14 crc16(2)
+    length field 0xFFFFFFFF: a u64 length follows the header.
 Framing, CRC and Reed-Solomon stay on the host CPU by design (BASELINE.json north_star)."""
 from __future__ import annotations
 
@@ -13,105 +19,115 @@ from zlib import crc32
 from ..common import FRM_SIGN, crc16_ansi
 from ..fourier.profiles import COMPACT, compact
 
+_LOSSLESS_TAIL = struct.Struct(">BBBI8xI")       # channels-1, dsize, codesize, srate, 8 zero bytes, fsize
+_HEAD_MIN, _HEAD_COMPACT, _HEAD_COMPACT_ECC, _HEAD_LOSSLESS = 9, 12, 16, 32
+
 
 def encode_pfb(profile: int, isecc: bool, little_endian: bool, bits: int) -> bytes:
-    return struct.pack("<B", (profile << 5) | (int(bool(isecc)) << 4) | (int(bool(little_endian)) << 3) | bits)
+    return bytes([(profile << 5) | (bool(isecc) << 4) | (bool(little_endian) << 3) | bits])
 
 
 def decode_pfb(pfb: bytes):
     v = pfb[0]
-    return v >> 5, bool(v >> 4 & 1), bool(v >> 3 & 1), v & 7
+    return v >> 5, bool(v & 0x10), bool(v & 0x08), v & 0x07
 
 
 def encode_css_prf1(channels: int, srate: int, fsize: int, force_flush: bool) -> bytes:
-    return struct.pack(">H", ((channels - 1) << 10) | (compact.get_srate_index(srate) << 6)
-                       | (compact.get_samples_index(fsize) << 1) | int(bool(force_flush)))
+    word = ((channels - 1) << 10) | (compact.get_srate_index(srate) << 6) | (compact.get_samples_index(fsize) << 1)
+    return (word | bool(force_flush)).to_bytes(2, "big")
 
 
 def decode_css_prf1(css: bytes):
-    v = struct.unpack(">H", css)[0]
-    return (v >> 10) + 1, compact.SRATES[v >> 6 & 15], compact.SAMPLES[v >> 1 & 31], bool(v & 1)
+    word = int.from_bytes(css, "big")
+    return (word >> 10) + 1, compact.SRATES[(word >> 6) & 0xF], compact.SAMPLES[(word >> 1) & 0x1F], bool(word & 1)
 
 
 class ASFH:
     def __init__(self):
-        self.frmbytes, self.buffer, self.all_set, self.header_bytes = 0, b"", False, 0
-        self.endian, self.bit_depth_index = False, 0
-        self.channels, self.srate, self.fsize = 0, 0, 0
-        self.ecc, self.ecc_dsize, self.ecc_codesize = False, 0, 0
-        self.profile, self.overlap_ratio = 0, 0
+        self.frmbytes = 0
+        self.buffer = b""                 # header bytes gathered so far (across `read` calls)
+        self.all_set = False
+        self.header_bytes = 0
+        self.endian = False
+        self.bit_depth_index = 0
+        self.channels = self.srate = self.fsize = 0
+        self.ecc = False
+        self.ecc_dsize = self.ecc_codesize = 0
+        self.profile = 0
+        self.overlap_ratio = 0
         self.crc = b""
 
     def criteq(self, other: "ASFH") -> bool:
-        return self.channels == other.channels and self.srate == other.srate
+        return (self.channels, self.srate) == (other.channels, other.srate)
+
+    # ------------------------------------------------------------------ writing
+    def _prefix(self, length: int) -> bytes:
+        return FRM_SIGN + length.to_bytes(4, "big") + encode_pfb(self.profile, self.ecc, self.endian, self.bit_depth_index)
 
     def write(self, frad: bytes) -> bytes:
-        head = FRM_SIGN + struct.pack(">I", len(frad)) + encode_pfb(self.profile, self.ecc, self.endian, self.bit_depth_index)
+        parts = [self._prefix(len(frad))]
         if self.profile in COMPACT:
-            head += encode_css_prf1(self.channels, self.srate, self.fsize, False)
-            head += struct.pack("B", max(self.overlap_ratio - 1, 0))
+            parts.append(encode_css_prf1(self.channels, self.srate, self.fsize, False))
+            parts.append(bytes([max(self.overlap_ratio - 1, 0)]))
             if self.ecc:
-                head += struct.pack("BB", self.ecc_dsize, self.ecc_codesize) + crc16_ansi(frad).to_bytes(2, "big")
+                parts.append(bytes([self.ecc_dsize, self.ecc_codesize]) + crc16_ansi(frad).to_bytes(2, "big"))
         else:
-            head += struct.pack("B", self.channels - 1) + struct.pack("BB", self.ecc_dsize, self.ecc_codesize)
-            head += struct.pack(">I", self.srate) + b"\x00" * 8 + struct.pack(">I", self.fsize)
-            head += crc32(frad).to_bytes(4, "big")
-        return head + frad
+            parts.append(_LOSSLESS_TAIL.pack(self.channels - 1, self.ecc_dsize, self.ecc_codesize, self.srate, self.fsize))
+            parts.append(crc32(frad).to_bytes(4, "big"))
+        parts.append(frad)
+        return b"".join(parts)
 
     def force_flush(self) -> bytes:
         if self.profile not in COMPACT:
             return b""
-        head = FRM_SIGN + b"\x00" * 4 + encode_pfb(self.profile, self.ecc, self.endian, self.bit_depth_index)
-        return head + encode_css_prf1(max(self.channels, 1), self.srate, self.fsize, True) + b"\x00"
+        return self._prefix(0) + encode_css_prf1(max(self.channels, 1), self.srate, self.fsize, True) + b"\x00"
 
-    def fill_buffer(self, buffer: bytes, target: int):
-        if len(self.buffer) < target:
-            cut = target - len(self.buffer)
-            self.buffer += buffer[:cut]
-            buffer = buffer[cut:]
-            if len(self.buffer) < target:
-                return False, buffer
-        self.header_bytes = target
-        return True, buffer
+    # ------------------------------------------------------------------ reading (incremental)
+    def fill_buffer(self, buffer: bytes, target_size: int):
+        """Move bytes from `buffer` into the header until it holds `target_size`; (done, rest)."""
+        missing = target_size - len(self.buffer)
+        if missing > 0:
+            self.buffer += buffer[:missing]
+            buffer = buffer[missing:]
+        done = len(self.buffer) >= target_size
+        if done:
+            self.header_bytes = target_size
+        return done, buffer
 
     def read(self, buffer: bytes):
-        ok, buffer = self.fill_buffer(buffer, 9)
-        if not ok:
+        done, buffer = self.fill_buffer(buffer, _HEAD_MIN)
+        if not done:
             return "Incomplete", buffer
-        self.frmbytes = struct.unpack(">I", self.buffer[4:8])[0]
-        self.profile, self.ecc, self.endian, self.bit_depth_index = decode_pfb(self.buffer[8:9])
-        if self.profile in COMPACT:
-            ok, buffer = self.fill_buffer(buffer, 12)
-            if not ok:
-                return "Incomplete", buffer
-            self.channels, self.srate, self.fsize, flush = decode_css_prf1(self.buffer[9:11])
+        h = self.buffer
+        self.frmbytes = int.from_bytes(h[4:8], "big")
+        self.profile, self.ecc, self.endian, self.bit_depth_index = decode_pfb(h[8:9])
+        compact_profile = self.profile in COMPACT
+        done, buffer = self.fill_buffer(buffer, _HEAD_COMPACT if compact_profile else _HEAD_LOSSLESS)
+        if not done:
+            return "Incomplete", buffer
+        h = self.buffer
+        if compact_profile:
+            self.channels, self.srate, self.fsize, flush = decode_css_prf1(h[9:11])
             if flush:
                 return "ForceFlush", buffer
-            self.overlap_ratio = self.buffer[11]
-            if self.overlap_ratio != 0:
-                self.overlap_ratio += 1
+            self.overlap_ratio = h[11] + 1 if h[11] else 0
             if self.ecc:
-                ok, buffer = self.fill_buffer(buffer, 16)
-                if not ok:
+                done, buffer = self.fill_buffer(buffer, _HEAD_COMPACT_ECC)
+                if not done:
                     return "Incomplete", buffer
-                self.ecc_dsize, self.ecc_codesize = struct.unpack("BB", self.buffer[12:14])
-                self.crc = self.buffer[14:16]
+                h = self.buffer
+                self.ecc_dsize, self.ecc_codesize, self.crc = h[12], h[13], h[14:16]
         else:
-            ok, buffer = self.fill_buffer(buffer, 32)
-            if not ok:
+            ch1, self.ecc_dsize, self.ecc_codesize, self.srate, self.fsize = _LOSSLESS_TAIL.unpack(h[9:28])
+            self.channels, self.crc = ch1 + 1, h[28:32]
+        if self.frmbytes == 0xFFFFFFFF:                      # 64-bit length extension
+            done, buffer = self.fill_buffer(buffer, self.header_bytes + 8)
+            if not done:
                 return "Incomplete", buffer
-            self.channels = self.buffer[9] + 1
-            self.ecc_dsize, self.ecc_codesize = struct.unpack("BB", self.buffer[10:12])
-            self.srate = struct.unpack(">I", self.buffer[12:16])[0]
-            self.fsize = struct.unpack(">I", self.buffer[24:28])[0]
-            self.crc = self.buffer[28:32]
-        if self.frmbytes == 0xFFFFFFFF:
-            ok, buffer = self.fill_buffer(buffer, self.header_bytes + 8)
-            if not ok:
-                return "Incomplete", buffer
-            self.frmbytes = struct.unpack(">Q", self.buffer[-8:])[0]
+            self.frmbytes = int.from_bytes(self.buffer[-8:], "big")
         self.all_set = True
         return "Complete", buffer
 
     def clear(self):
-        self.all_set, self.buffer = False, b""
+        self.all_set = False
+        self.buffer = b""
