@@ -67,12 +67,13 @@ class Workload:
             lib.plan_prepare(self.tail, False)
         nb = lib.payload_bytes(FSIZE, CHANNELS, BITS)
         self.pay = torch.empty((self.n_full, nb), dtype=torch.uint8, device=device)
-        self.absmax = torch.empty(self.n_full, dtype=torch.float64, device=device)
+        self.absmax_all = torch.empty(self.n_full + 1, dtype=torch.float64, device=device)   # main frames + tail frame
+        self.absmax = self.absmax_all[:self.n_full]
         self.out = torch.empty((self.n_full, FSIZE, CHANNELS), dtype=torch.float64, device=device)
         if self.tail:
             nbt = lib.payload_bytes(self.tail, CHANNELS, BITS)
             self.pay_t = torch.empty((1, nbt), dtype=torch.uint8, device=device)
-            self.absmax_t = torch.empty(1, dtype=torch.float64, device=device)
+            self.absmax_t = self.absmax_all[self.n_full:]
             self.out_t = torch.empty((1, self.tail, CHANNELS), dtype=torch.float64, device=device)
         self.tail_pcm = self.pcm[self.n_full * FSIZE:]
         self.over = torch.zeros((), dtype=torch.bool, device=device)
@@ -96,9 +97,8 @@ class Workload:
     def overflow_check(self):
         """The reference's per-frame overflow test (profile0.py:24-26): evaluated on the device every
         step over all frames; the host reads the sticky flag once, after the timed region."""
-        self.over |= (self.absmax > core.FLOAT_MAX[BITS]).any()
-        if self.tail:
-            self.over |= (self.absmax_t > core.FLOAT_MAX[BITS]).any()
+        n = self.n_full + (1 if self.tail else 0)
+        self.over |= (self.absmax_all[:n] > core.FLOAT_MAX[BITS]).any()      # per-frame comparison, like the reference
 
 
 def cpu_baseline(pcm_host: np.ndarray, n_frames: int, min_seconds: float = 12.0):
