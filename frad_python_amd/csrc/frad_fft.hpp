@@ -32,8 +32,12 @@ template <bool INV, typename T> __device__ __forceinline__ cx<T> mul_mi(cx<T> a)
 // 32 banks) and 15 for 8-byte slots.  Lane-contiguous accesses stay inside aligned 16-slot rows
 // (conflict-free for every ds_read/ds_write lane group) and the first pass's lane-strided Stockham
 // scatter (stride R slots) is spread over all banks instead of hitting one.
+// SH == 100 selects the layout of the 4-16-16 inverse plan (frad_persistent.hpp): slot bits 8-9 and bit 6 are
+// folded into bits 2-3 / 2, which keeps its three access shapes (lane + 64 j, lane/4 + 16 j + 256 (lane & 3),
+// and the 16-strided Stockham scatter of its middle pass) on distinct banks.
 template <typename T, int SH> __device__ __forceinline__ int phys(int i) {
     if constexpr (SH < 0) return i;
+    else if constexpr (SH == 100) return i ^ ((((i >> 8) & 3) << 2) ^ (((i >> 6) & 1) << 2));
     else return i ^ ((i >> SH) & (sizeof(cx<T>) == 16 ? 7 : 15));
 }
 // phys(t + c) for c a multiple of 16: the swizzle only touches the low 3-4 bits, which c leaves alone, so
@@ -41,6 +45,7 @@ template <typename T, int SH> __device__ __forceinline__ int phys(int i) {
 // takes two values at most over a pass, i.e. two VALU ops instead of four per access.
 template <typename T, int SH> __device__ __forceinline__ int phys_tc(int t, int c) {
     if constexpr (SH < 0) return t + c;
+    else if constexpr (SH == 100) return phys<T, SH>(t + c);
     else return c + (t ^ (((t >> SH) + (c >> SH)) & (sizeof(cx<T>) == 16 ? 7 : 15)));
 }
 __host__ __device__ constexpr int padded_slots(int m) { return m; }

@@ -74,9 +74,9 @@ int build_tables(int log2m, Tables& out) {
     HIPCHK(hipMemcpy(out.tw, tw.data(), tw.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(out.post, post.data(), post.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
     std::vector<unsigned char> blob;
-    for (int which = 0; which < 2; ++which) {
+    for (int which = 0; which < 3; ++which) {                 // plan A, plan B, inverse plan I
         if (!pers_blob_build(log2m, sizeof(T) == 4, which, blob, unit_neg)) continue;
-        void*& dst = which ? out.blob_b : out.blob;
+        void*& dst = which == 0 ? out.blob : which == 1 ? out.blob_b : out.blob_i;
         HIPCHK(hipMalloc(&dst, blob.size()));
         HIPCHK(hipMemcpy(dst, blob.data(), blob.size(), hipMemcpyHostToDevice));
     }
@@ -235,7 +235,7 @@ int frad_plan_prepare(int32_t N, int32_t compute_f32) {
 
 void frad_plan_clear(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (auto& kv : g_tables) { (void)hipFree(kv.second.tw); (void)hipFree(kv.second.post); if (kv.second.blob) (void)hipFree(kv.second.blob); if (kv.second.blob_b) (void)hipFree(kv.second.blob_b); }
+    for (auto& kv : g_tables) { (void)hipFree(kv.second.tw); (void)hipFree(kv.second.post); if (kv.second.blob) (void)hipFree(kv.second.blob); if (kv.second.blob_b) (void)hipFree(kv.second.blob_b); if (kv.second.blob_i) (void)hipFree(kv.second.blob_i); }
     for (auto& kv : g_direct) (void)hipFree(kv.second.ct);
     g_tables.clear(); g_direct.clear();
 }

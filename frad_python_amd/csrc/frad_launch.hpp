@@ -7,7 +7,7 @@
 
 namespace frad {
 
-struct Tables { void* tw = nullptr; void* post = nullptr; void* blob = nullptr; void* blob_b = nullptr; };   // blob: LDS image of the persistent kernels
+struct Tables { void* tw = nullptr; void* post = nullptr; void* blob = nullptr; void* blob_b = nullptr; void* blob_i = nullptr; };   // blob: LDS image of the persistent kernels
 
 // launch geometry of the LDS-resident FFT kernels
 struct FastCfg {

@@ -68,7 +68,7 @@ void go_fwd_unit(const void* blob, int cc, size_t lds, int grid, hipStream_t s, 
     }
 }
 template <int BITS>
-void go_inv_unit(const void* blob, int cc, size_t lds, int grid, hipStream_t s, const unsigned char* pay, double* out, const Geom& g) {
+void go_inv_unit_a(const void* blob, int cc, size_t lds, int grid, hipStream_t s, const unsigned char* pay, double* out, const Geom& g) {
     const cx<double>* b = static_cast<const cx<double>*>(blob);
     if (cc == 2) {
         allow_lds(k_p0_inv_unit<PlanA10, BITS, 2>, lds);
@@ -76,6 +76,22 @@ void go_inv_unit(const void* blob, int cc, size_t lds, int grid, hipStream_t s, 
     } else {
         allow_lds(k_p0_inv_unit<PlanA10, BITS, 1>, lds);
         hipLaunchKernelGGL((k_p0_inv_unit<PlanA10, BITS, 1>), dim3(grid), dim3(512), lds, s, pay, out, b, g);
+    }
+}
+// default: the unfused 16-16-4 inverse (plan A).  FRAD_TUNE_INV_PLAN=I selects the 4-16-16 plan with the pair step
+// fused into the first pass; measured equal within noise on MI355X (decode already runs at ~80 % of the achievable
+// HBM rate), and plan A leaves a little LDS headroom.
+bool inv_plan_a() { const char* e = getenv("FRAD_TUNE_INV_PLAN"); return !(e && (e[0] == 'I' || e[0] == 'i')); }
+
+template <int BITS>
+void go_inv_unit(const void* blob, int cc, size_t lds, int grid, hipStream_t s, const unsigned char* pay, double* out, const Geom& g) {
+    const cx<double>* b = static_cast<const cx<double>*>(blob);
+    if (cc == 2) {
+        allow_lds(k_p0_inv_unit<PlanI10, BITS, 2>, lds);
+        hipLaunchKernelGGL((k_p0_inv_unit<PlanI10, BITS, 2>), dim3(grid), dim3(512), lds, s, pay, out, b, g);
+    } else {
+        allow_lds(k_p0_inv_unit<PlanI10, BITS, 1>, lds);
+        hipLaunchKernelGGL((k_p0_inv_unit<PlanI10, BITS, 1>), dim3(grid), dim3(512), lds, s, pay, out, b, g);
     }
 }
 bool unit_sync() { const char* e = getenv("FRAD_TUNE_PERS_UNIT"); return !(e && e[0] == '0'); }
@@ -117,7 +133,11 @@ static void fill_blob(std::vector<unsigned char>& bytes, void (*unit)(long long,
 size_t pers_blob_build(int log2m, bool f32, int which, std::vector<unsigned char>& bytes,
                        void (*unit)(long long, long long, long double&, long double&)) {
     bytes.clear();
-    if (log2m == 10 && !f32) { if (which == 0) fill_blob<double, PlanA10>(bytes, unit); else fill_blob<double, PlanB10>(bytes, unit); }
+    if (log2m == 10 && !f32) {
+        if (which == 0) fill_blob<double, PlanA10>(bytes, unit);
+        else if (which == 1) fill_blob<double, PlanB10>(bytes, unit);
+        else fill_blob<double, PlanI10>(bytes, unit);
+    }
     else if (log2m == 11 && f32 && which == 0) fill_blob<float, PlanA11>(bytes, unit);
     return bytes.size();
 }
@@ -168,18 +188,33 @@ int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const 
 
 int launch_p0_inv_pers(const FastCfg& c, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb, Geom g) {
     if (disabled() || tb.blob == nullptr || c.cg != g.C || c.log2m != 10 || g.C > 2 || g.cc_fast != g.C || g.in_mode != g.C) return 0;
-    if (unit_sync() && !plan_b()) {
+    if (unit_sync() && !plan_b() && inv_plan_a()) {
         const int upb = 8 / g.C;
-        const size_t lds = (size_t)pers_table_bytes<double, PlanA10>() + 128 + 8 * 1024 * 16;
+        const size_t lds = (size_t)pers_table_bytes<double, PlanA10>() + 32 + 8 * 1024 * 16;
         const long long nb = (g.n_frames + upb - 1) / upb, cap = (long long)cu_count() * blocks_per_cu();
         const int grid = (int)(nb < cap ? nb : cap);
         switch (g.bits) {
-            case 12: go_inv_unit<12>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
-            case 16: go_inv_unit<16>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
-            case 24: go_inv_unit<24>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
-            case 32: go_inv_unit<32>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
-            case 48: go_inv_unit<48>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
-            default: go_inv_unit<64>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+            case 12: go_inv_unit_a<12>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+            case 16: go_inv_unit_a<16>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+            case 24: go_inv_unit_a<24>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+            case 32: go_inv_unit_a<32>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+            case 48: go_inv_unit_a<48>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+            default: go_inv_unit_a<64>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+        }
+        return 1;
+    }
+    if (unit_sync() && !plan_b() && tb.blob_i != nullptr) {
+        const int upb = 8 / g.C;
+        const size_t lds = (size_t)pers_table_bytes<double, PlanI10>() + 32 + 8 * 1024 * 16;   // = 163840 B, all of a CU's LDS
+        const long long nb = (g.n_frames + upb - 1) / upb, cap = (long long)cu_count() * blocks_per_cu();
+        const int grid = (int)(nb < cap ? nb : cap);
+        switch (g.bits) {
+            case 12: go_inv_unit<12>(tb.blob_i, g.C, lds, grid, s, pay, out, g); break;
+            case 16: go_inv_unit<16>(tb.blob_i, g.C, lds, grid, s, pay, out, g); break;
+            case 24: go_inv_unit<24>(tb.blob_i, g.C, lds, grid, s, pay, out, g); break;
+            case 32: go_inv_unit<32>(tb.blob_i, g.C, lds, grid, s, pay, out, g); break;
+            case 48: go_inv_unit<48>(tb.blob_i, g.C, lds, grid, s, pay, out, g); break;
+            default: go_inv_unit<64>(tb.blob_i, g.C, lds, grid, s, pay, out, g); break;
         }
         return 1;
     }

@@ -24,6 +24,7 @@ namespace frad {
 // swizzle shift (log2 R1).
 struct PlanA10 { static constexpr int LOG2M = 10, TEAM = 64,  SH = 4, R1 = 16, R2 = 16, R3 = 4, R4 = 0; };  // 2 waves/SIMD
 struct PlanB10 { static constexpr int LOG2M = 10, TEAM = 128, SH = 3, R1 = 8,  R2 = 8,  R3 = 8, R4 = 2; };  // 4 waves/SIMD
+struct PlanI10 { static constexpr int LOG2M = 10, TEAM = 64,  SH = 100, R1 = 4, R2 = 16, R3 = 16, R4 = 0; };  // inverse, fused first pass
 struct PlanA11 { static constexpr int LOG2M = 11, TEAM = 128, SH = 4, R1 = 16, R2 = 16, R3 = 8, R4 = 0; };
 
 // LDS table blob of a plan (units: complex slots): [pass-2][pass-3][pass-4 tables][w_k][g_k]
@@ -111,6 +112,79 @@ __device__ __forceinline__ void fft_last_pass_dct(cx<T>* buf, int l, const cx<T>
     pair(lane0 ? 128 : 256 - l, z[3][0], sel(z[3][3], z[0][3]));
     if (lane0) pair(384, z[3][1], z[3][2]);
     team_sync<TEAM, true>();
+}
+
+// Inverse counterpart (plan I: 4 16 16): the DCT pair step runs on registers and feeds the FIRST radix-4
+// pass directly.  Lane l owns butterflies k0 in {l, 64+l, 192-l, 256-l} (lane 0: {0, 64, 192, 128}), i.e.
+// exactly the 16 points Z'[k0 + 256 j] that its eight (k, M-k) pairs produce from X[k], X[N-k], X[M-k], X[M+k].
+// Results go to slot k0 + 256 j (lane-contiguous); the middle pass reads them from there.
+template <typename PL>
+__device__ __forceinline__ void dct_pre_first_pass(cx<double>* buf, int l, const cx<double>* lpost) {
+    using T = double;
+    constexpr int M = 1 << PL::LOG2M, N = 2 * M, SH = PL::SH, TEAM = PL::TEAM;
+    static_assert(M == 1024 && TEAM == 64 && PL::R1 == 4, "plan I, N = 2048");
+    constexpr int GOFF = M / 2 + 1;
+    const bool lane0 = (l == 0);
+    struct PairOut { cx<T> zk, zm; };
+    auto pair = [&](int k) -> PairOut {                      // -> Z'[k], Z'[M - k]
+        const T xk = real_slot<T, SH>(buf, k);
+        const T xnk = k > 0 ? real_slot<T, SH>(buf, N - k) : (T)0;
+        const T a = real_slot<T, SH>(buf, M - k), b = real_slot<T, SH>(buf, k > 0 ? M + k : M);
+        const cx<T> u = {xk, -xnk};
+        const cx<T> s = {(a + b) * K<T>::s2, (b - a) * K<T>::s2};
+        const cx<T> A = cmul(u + s, conj(lpost[k])), B = cmul(u - s, conj(lpost[k + GOFF]));
+        return PairOut{A + B, conj(A - B)};
+    };
+    // group {64+l, 192-l}
+    const PairOut p0 = pair(64 + l), p1 = pair(320 + l), p2 = pair(448 - l), p3 = pair(192 - l);
+    // group {l, 256-l}; lane 0: {0, 128}
+    const PairOut q0 = pair(l), q1 = pair(256 + l), q2 = pair(512 - l), q3 = pair(lane0 ? 128 : 256 - l);
+    PairOut q4 = q3;
+    if (lane0) q4 = pair(384);
+    team_sync<TEAM, true>();                                 // all X read: the buffer may be overwritten
+    auto sel = [&](cx<T> a, cx<T> b) { return cx<T>{lane0 ? a.x : b.x, lane0 ? a.y : b.y}; };
+    cx<T> z[4][4];
+    // butterfly 64+l : Z'[64+l], [320+l], [576+l] = M-(448-l), [832+l] = M-(192-l)
+    z[1][0] = p0.zk; z[1][1] = p1.zk; z[1][2] = p2.zm; z[1][3] = p3.zm;
+    // butterfly 192-l: Z'[192-l], [448-l], [704-l] = M-(320+l), [960-l] = M-(64+l)
+    z[2][0] = p3.zk; z[2][1] = p2.zk; z[2][2] = p1.zm; z[2][3] = p0.zm;
+    // butterfly l     : Z'[l], [256+l], [512+l] = M-(512-l), [768+l] = M-(256-l);  lane 0: Z'[0], [256], [512], [768] = M-256
+    z[0][0] = q0.zk; z[0][1] = q1.zk; z[0][2] = sel(q2.zk, q2.zm); z[0][3] = sel(q1.zm, q3.zm);
+    // butterfly 256-l : Z'[256-l], [512-l], [768-l] = M-(256+l), [1024-l] = M-l;  lane 0 (k0 = 128): Z'[128], [384], [640], [896]
+    z[3][0] = q3.zk; z[3][1] = sel(q4.zk, q2.zk); z[3][2] = sel(q4.zm, q1.zm); z[3][3] = sel(q3.zm, q0.zm);
+    const int k0[4] = {l, 64 + l, 192 - l, lane0 ? 128 : 256 - l};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        dft<4, true>(z[b]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) buf[phys<T, SH>(k0[b] + 256 * j)] = z[b][j];
+    }
+    team_sync<TEAM, true>();
+}
+
+// middle pass of plan I: radix 16, NS = 4, reading the first pass's results where it left them
+// (butterfly b, output j at slot b + 256 j) and writing in Stockham order.
+template <typename PL>
+__device__ __forceinline__ void fft_middle_pass_inv(cx<double>* buf, int t, const cx<double>* ptab) {
+    using T = double;
+    constexpr int M = 1 << PL::LOG2M, SH = PL::SH, TEAM = PL::TEAM, R = 16, NS = 4;
+    cx<T> v[R];
+    const int k = t & 3;
+#pragma unroll
+    for (int j = 0; j < R; ++j) v[j] = buf[phys<T, SH>((t >> 2) + 16 * j + 256 * k)];     // Stockham index t + 64 j of pass 1
+    team_sync<TEAM, true>();
+#pragma unroll
+    for (int j = 1; j < R; ++j) {
+        cx<T> w = ptab[(j - 1) * NS + k];
+        w.y = -w.y;
+        v[j] = cmul(v[j], w);
+    }
+    dft<R, true>(v);
+    const int base = (t - k) * R + k;
+#pragma unroll
+    for (int j = 0; j < R; ++j) buf[phys<T, SH>(base + j * NS)] = v[j];
+    team_sync<TEAM, true>();
+    (void)M;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -628,7 +702,7 @@ __global__ void __launch_bounds__(512, 2)
 k_p0_inv_unit(const unsigned char* __restrict__ payload, double* __restrict__ out, const cx<double>* __restrict__ blob, Geom g) {
     constexpr int LOG2M = PL::LOG2M, M = 1 << LOG2M, N = 2 * M, TEAM = PL::TEAM, SH = PL::SH;
     static_assert(TEAM == 64, "one wave per channel-frame");
-    constexpr int TB = pers_table_bytes<double, PL>(), CTRB = 128;
+    constexpr int TB = pers_table_bytes<double, PL>(), CTRB = 32;      // 8 unit-barrier words (plan I fills the 160 KiB exactly)
     constexpr int U = unit_values(BITS), UB = unit_bytes(BITS);
     constexpr int V = U > 2 * CC ? U : 2 * CC, KB = V / CC, UPV = V / U;
     constexpr int TPT = N / (V * TEAM);
@@ -637,7 +711,7 @@ k_p0_inv_unit(const unsigned char* __restrict__ payload, double* __restrict__ ou
     FRAD_DYN_SMEM(smem);
     pers_load_tables<double, PL>(smem, blob);
     unsigned* ctrs = reinterpret_cast<unsigned*>(smem + TB);
-    if (threadIdx.x < 16) ctrs[threadIdx.x] = 0;
+    if (threadIdx.x < 8) ctrs[threadIdx.x] = 0;
     const cx<double>* ltab = reinterpret_cast<const cx<double>*>(smem);
     const cx<double>* lpost = ltab + PersLayout<PL>::OFFP;
     const int unit = threadIdx.x / UTH, utid0 = threadIdx.x - unit * UTH;
@@ -693,8 +767,14 @@ k_p0_inv_unit(const unsigned char* __restrict__ payload, double* __restrict__ ou
         int t = utid & 63, co = (utid >> 6) * M;
         FRAD_OPAQUE(t); FRAD_OPAQUE(co);
         cx<double>* buf = reinterpret_cast<cx<double>*>(data) + co;
-        dct_pre_inverse<double, LOG2M, 1, TEAM, SH, true>(buf, t, lpost);
-        fft_team_lt<double, PL, true>(buf, t, ltab);
+        if constexpr (PL::R1 == 4) {                          // plan I: pair step + first pass on registers
+            dct_pre_first_pass<PL>(buf, t, lpost);
+            fft_middle_pass_inv<PL>(buf, t, ltab + PersLayout<PL>::OFF2);
+            fft_pass_lt<double, M, TEAM, PL::R3, PersLayout<PL>::NS3, true, SH>(buf, t, ltab + PersLayout<PL>::OFF3);
+        } else {
+            dct_pre_inverse<double, LOG2M, 1, TEAM, SH, true>(buf, t, lpost);
+            fft_team_lt<double, PL, true>(buf, t, ltab);
+        }
 #pragma unroll
         for (int i = 0; i < TPT; ++i)
 #pragma unroll
