@@ -85,18 +85,18 @@ class Workload:
         """encode + decode of the short last frame, on the side stream"""
         if not self.tail:
             return
-        self.side.wait_stream(torch.cuda.current_stream())          # ordered after the previous step's overflow check
+        self.side.wait_stream(torch.cuda.current_stream())          # after this step's encode launch (and the previous step)
         with torch.cuda.stream(self.side):
             core.analogue_batch(0, self.tail_pcm, "s16le", 1, self.tail, CHANNELS, BITS, False,
                                 check_overflow=False, out=self.pay_t, absmax=self.absmax_t)
             core.digital_batch(0, self.pay_t, 1, self.tail, CHANNELS, BITS, False, out=self.out_t)
 
     def encode(self, ev=None):
-        self.tail_frame()
         if ev: ev[0].record()
         core.analogue_batch(0, self.pcm, "s16le", self.n_full, FSIZE, CHANNELS, BITS, False,
                             check_overflow=False, out=self.pay, absmax=self.absmax)
         if ev: ev[1].record()
+        self.tail_frame()            # queued behind the resident encode kernel: fills CUs as its blocks retire
 
     def decode(self, ev=None):
         if ev: ev[0].record()
