@@ -137,9 +137,12 @@ FastCfg fast_cfg(int N, int C, bool f32) {
         // one frame's channels exceed a CU: transform `cg` channels per pass (per-value I/O)
         if (c.team < 64) return c;
         int cg = C;
-        while (cg > 1 && ((long long)cg * c.team > 1024 || (size_t)cg * per_cf > (size_t)kLdsBytes)) --cg;
+        // <= 512 threads for float64: two waves per SIMD leave the radix-16 butterflies their 256 registers
+        const long long tmax = f32 ? 1024 : 512;
+        while (cg > 1 && ((long long)cg * c.team > tmax || (size_t)cg * per_cf > (size_t)kLdsBytes)) --cg;
         if ((long long)cg * c.team > 1024 || (size_t)cg * per_cf > (size_t)kLdsBytes) return c;
         if (cg > 1 && (cg & 1)) --cg;                       // even groups keep 12-bit pairs together
+        if (const char* e = getenv("FRAD_TUNE_CG")) { const int v = atoi(e); if (v >= 1 && v <= cg && (v == 1 || !(v & 1))) cg = v; }
         c.cg = cg; c.fpb = 1; c.threads = cg * c.team; c.lds = (size_t)cg * per_cf; c.ok = true;
         return c;
     }

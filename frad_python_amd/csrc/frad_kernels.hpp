@@ -750,8 +750,8 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? 2 : 1)) k_p0_fwd(const un
 // Channel-group variant: one frame per block, `g.cg` channels per pass (see above).  A kernel of
 // its own so that the common kernel's register allocation is not disturbed by the second copy of
 // the transform.
-template <typename T, int LOG2M, int LG>
-__global__ void __launch_bounds__(1024) k_p0_fwd_grp(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload,
+template <typename T, int LOG2M, int LG, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_p0_fwd_grp(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload,
                                                       double* absmax, const cx<T>* __restrict__ tw, const cx<T>* __restrict__ post, Geom g) {
     constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM, SLOTS = padded_slots(M), SH = Plan<LOG2M>::SH;
     FRAD_DYN_SMEM(smem);
@@ -762,8 +762,9 @@ __global__ void __launch_bounds__(1024) k_p0_fwd_grp(const unsigned char* __rest
         const int cgn = g.C - c0 < g.cg ? g.C - c0 : g.cg;
         stage_in_pcm_group<T, LG, SH>(pcm, 0, g, f0, SLOTS, c0, cgn);
         __syncthreads();
-        fft_team<T, LOG2M, false>(buf, t, tw);
-        dct_post<T, LOG2M>(buf, t, post);
+        int tt = t; FRAD_OPAQUE(tt);                          // keep per-lane LDS addresses out of the loop preheader
+        fft_team<T, LOG2M, false>(buf, tt, tw);
+        dct_post<T, LOG2M>(buf, tt, post);
         __syncthreads();
         pack_out_group<T, SH>(0, payload, absmax, g, f0, SLOTS, c0, cgn);
         __syncthreads();
@@ -796,8 +797,8 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? 2 : 1)) k_p0_inv(const un
     else store_pcm_f64<SH, true>(0, out, g, f0, nfl, SLOTS);
 }
 
-template <int LOG2M>
-__global__ void __launch_bounds__(1024) k_p0_inv_grp(const unsigned char* __restrict__ payload, double* __restrict__ out,
+template <int LOG2M, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_p0_inv_grp(const unsigned char* __restrict__ payload, double* __restrict__ out,
                                                       const cx<double>* __restrict__ tw, const cx<double>* __restrict__ post, Geom g) {
     constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM, SLOTS = padded_slots(M), SH = Plan<LOG2M>::SH;
     FRAD_DYN_SMEM(smem);
@@ -808,8 +809,9 @@ __global__ void __launch_bounds__(1024) k_p0_inv_grp(const unsigned char* __rest
         const int cgn = g.C - c0 < g.cg ? g.C - c0 : g.cg;
         unpack_in_group<SH>(payload, 0, g, f0, SLOTS, c0, cgn);
         __syncthreads();
-        dct_pre_inverse<double, LOG2M>(buf, t, post);
-        fft_team<double, LOG2M, true>(buf, t, tw);
+        int tt = t; FRAD_OPAQUE(tt);                          // keep per-lane LDS addresses out of the loop preheader
+        dct_pre_inverse<double, LOG2M>(buf, tt, post);
+        fft_team<double, LOG2M, true>(buf, tt, tw);
         __syncthreads();
         store_pcm_group<SH>(0, out, g, f0, SLOTS, c0, cgn);
         __syncthreads();

@@ -175,7 +175,7 @@ int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const 
     const long long cap = (long long)cu_count() * blocks_per_cu();
     const int grid = (int)(ngroups < cap ? ngroups : cap);
     const int ng = (int)ngroups;
-    if (f32) go_fwd<float, PlanA11, 2, 1024>(tb.blob, threads, lds, grid, s, pcm, pay, am, g, ng, ao);
+    if (f32) go_fwd<float, PlanA11, 2, 512>(tb.blob, threads, lds, grid, s, pcm, pay, am, g, ng, ao);
     else if (pb) {
         if (lg == 1) go_fwd<double, PlanB10, 1, 1024>(tb.blob_b, threads, lds, grid, s, pcm, pay, am, g, ng, ao);
         else go_fwd<double, PlanB10, 2, 1024>(tb.blob_b, threads, lds, grid, s, pcm, pay, am, g, ng, ao);

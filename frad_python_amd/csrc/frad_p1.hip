@@ -5,6 +5,10 @@
 
 #include <climits>
 #include <cmath>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
 
 using namespace frad;
 
@@ -30,6 +34,32 @@ int p1_scale_bits(int bits) {                    // profile1.py:16: unknown dept
     return 16;
 }
 
+thread_local int g_last = 0;
+
+// per-bin band index tables, one per (device, N, snapped rate); a few KiB each, kept for the process lifetime
+std::mutex g_band_mu;
+std::map<std::tuple<int, int, int>, unsigned char*> g_band;
+
+int band_table(int N, int sr, const P1Tables& tb, const unsigned char** out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return FRAD_E_HIP;
+    std::lock_guard<std::mutex> lk(g_band_mu);
+    auto key = std::make_tuple(dev, N, sr);
+    auto it = g_band.find(key);
+    if (it != g_band.end()) { *out = it->second; return FRAD_OK; }
+    std::vector<unsigned char> host((size_t)N, 255);
+    for (int b = 0; b < P1_BANDS - 1; ++b) {
+        const int a = tb.edge[b] < N ? tb.edge[b] : N, e = tb.edge[b + 1] < N ? tb.edge[b + 1] : N;
+        for (int k = a; k < e; ++k) if (host[k] == 255) host[k] = (unsigned char)b;
+    }
+    unsigned char* d = nullptr;
+    if (hipMalloc(&d, (size_t)N) != hipSuccess) return FRAD_E_NOMEM;
+    if (hipMemcpy(d, host.data(), (size_t)N, hipMemcpyHostToDevice) != hipSuccess) return FRAD_E_HIP;
+    g_band[key] = d; *out = d;
+    return FRAD_OK;
+}
+#define P1CHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_last = (int)e_; return FRAD_E_HIP; } } while (0)
+
 int make_tables(int N, int srate, int bits, double loss_level, P1Tables& tb) {
     const int sr = valid_srate(srate);
     if (sr < 0) return FRAD_E_INVALID;
@@ -48,11 +78,8 @@ int make_tables(int N, int srate, int bits, double loss_level, P1Tables& tb) {
     }
     tb.scale = ldexp(1.0, p1_scale_bits(bits) - 1);
     tb.loss = fabs(loss_level) > 0.125 ? fabs(loss_level) : 0.125;
-    return FRAD_OK;
+    return band_table(N, sr, tb, &tb.band_of);
 }
-
-thread_local int g_last = 0;
-#define P1CHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_last = (int)e_; return FRAD_E_HIP; } } while (0)
 
 template <int LOG2M>
 void go_fwd(int lg, const FastCfg& c, size_t lds, dim3 grid, hipStream_t s, const unsigned char* pcm, int32_t* q, int32_t* tq,

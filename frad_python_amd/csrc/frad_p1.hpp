@@ -17,6 +17,7 @@ constexpr int P1_BANDS = 27;
 
 // per launch constants, built on the host (see frad_p1.hip)
 struct P1Tables {
+    const unsigned char* band_of;  // device table [N]: band j with start_j <= k < start_{j+1} (j <= 25), 255 = none
     int edge[P1_BANDS + 1];      // band edges in bins, NOT clipped (p1tools.py:15-16)
     double floor_[P1_BANDS];     // min(ATH(band centre), 1.0)            (p1tools.py:25-31)
     double scale;                // 2^(bits-1)                            (profile1.py:9-10)
@@ -29,21 +30,20 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
-// |x|^0.75 with sign (p1tools.py:43) and its inverse |x|^(1/0.75) (p1tools.py:44)
-__device__ __forceinline__ double p1_quant(double x) { const double a = fabs(x); return copysign(pow(a, 0.75), x) * (a != 0.0); }
+// |x|^0.75 with sign (p1tools.py:43) and its inverse |x|^(1/0.75) (p1tools.py:44).  a^0.75 = sqrt(a) * sqrt(sqrt(a)):
+// two correctly rounded square roots and one product (<= 1.5 ulp) instead of a generic pow -- the value is rounded
+// to an integer right after, so only results within ~1e-16 of a half-integer could differ from pow's.
+__device__ __forceinline__ double p1_quant(double x) {
+    const double a = fabs(x), r = sqrt(a);
+    return copysign(r * sqrt(r), x) * (a != 0.0);
+}
 __device__ __forceinline__ double p1_dequant(double x) { const double a = fabs(x); return copysign(pow(a, 1.0 / 0.75), x) * (a != 0.0); }
 
 // linear ramp between consecutive band starts, endpoint excluded (np.linspace as mapping_from_opus
 // uses it, p1tools.py:35-41); bins beyond the last start map to 0.
-__device__ __forceinline__ double p1_spread(const double* thres, const int* edge, int N, int k) {
-    // band j with start_j <= k < start_{j+1}, starts clipped to N, j in [0, 25]
-    int j = -1;
-#pragma unroll 1
-    for (int b = 0; b < P1_BANDS - 1; ++b) {
-        const int a = edge[b] < N ? edge[b] : N, e = edge[b + 1] < N ? edge[b + 1] : N;
-        if (k >= a && k < e) { j = b; break; }
-    }
-    if (j < 0) return 0.0;
+__device__ __forceinline__ double p1_spread(const double* thres, const int* edge, const unsigned char* band_of, int N, int k) {
+    const int j = band_of[k];                             // host-built: start_j <= k < start_{j+1}, starts clipped to N
+    if (j >= P1_BANDS - 1) return 0.0;
     const int a = edge[j] < N ? edge[j] : N, e = edge[j + 1] < N ? edge[j + 1] : N;
     const double start = thres[j], delta = thres[j + 1] - start, num = (double)(e - a);
     const double step = delta / num;
@@ -54,7 +54,7 @@ __device__ __forceinline__ double p1_spread(const double* thres, const int* edge
 
 // K7 epilogue: X[k] of `nfl` frames x C channels sit in LDS (xslot<double, SH>); scratch = 27*C*nfl doubles.
 template <int SH>
-__device__ FRAD_NOINLINE void p1_quantise(int smem_off, int scratch_off, int slots, const P1Tables& tb, const Geom& g,
+__device__ FRAD_NOINLINE void p1_quantise(int smem_off, int scratch_off, int slots, const P1Tables tb, const unsigned char* __restrict__ band_of, const Geom& g,
                                           long long f0, int nfl, int32_t* __restrict__ q, int32_t* __restrict__ tq) {
     FRAD_DYN_SMEM(base);
     unsigned char* smem = base + smem_off;
@@ -89,7 +89,7 @@ __device__ FRAD_NOINLINE void p1_quantise(int smem_off, int scratch_off, int slo
     for (int i = threadIdx.x; i < nfl * NC; i += blockDim.x) {
         const int fl = i / NC, r = i - fl * NC, k = r / C, c = r - k * C;
         const double x = xslot<double, SH>(smem, fl * C + c, slots, k);
-        const double div = p1_spread(thres + (fl * C + c) * P1_BANDS, tb.edge, N, k);
+        const double div = p1_spread(thres + (fl * C + c) * P1_BANDS, tb.edge, band_of, N, k);
         const double m = (div == 0.0) ? 0.0 * x : x / div;                // x / inf keeps the sign of x
         q[(f0 + fl) * (long long)NC + r] = (int32_t)rint(p1_quant(m * tb.scale));
     }
@@ -97,7 +97,7 @@ __device__ FRAD_NOINLINE void p1_quantise(int smem_off, int scratch_off, int slo
 
 // K8 prologue: q / tq -> X[k] in LDS.
 template <int SH>
-__device__ FRAD_NOINLINE void p1_dequantise(int smem_off, int scratch_off, int slots, const P1Tables& tb, const Geom& g,
+__device__ FRAD_NOINLINE void p1_dequantise(int smem_off, int scratch_off, int slots, const P1Tables tb, const unsigned char* __restrict__ band_of, const Geom& g,
                                             long long f0, int nfl, const int32_t* __restrict__ q, const int32_t* __restrict__ tq) {
     FRAD_DYN_SMEM(base);
     unsigned char* smem = base + smem_off;
@@ -113,7 +113,7 @@ __device__ FRAD_NOINLINE void p1_dequantise(int smem_off, int scratch_off, int s
     for (int i = threadIdx.x; i < nfl * NC; i += blockDim.x) {
         const int fl = i / NC, r = i - fl * NC, k = r / C, c = r - k * C;
         const double v = p1_dequant((double)q[(f0 + fl) * (long long)NC + r]) / tb.scale;
-        xslot<double, SH>(smem, fl * C + c, slots, k) = v * p1_spread(thres + (fl * C + c) * P1_BANDS, tb.edge, N, k);
+        xslot<double, SH>(smem, fl * C + c, slots, k) = v * p1_spread(thres + (fl * C + c) * P1_BANDS, tb.edge, band_of, N, k);
     }
 }
 
@@ -133,7 +133,7 @@ k_p1_fwd(const unsigned char* __restrict__ pcm, int32_t* __restrict__ q, int32_t
     fft_team<double, LOG2M, false>(buf, t, tw);
     dct_post<double, LOG2M>(buf, t, post);
     __syncthreads();
-    p1_quantise<SH>(0, g.fpb * g.C * SLOTS * 16, SLOTS, tb, g, f0, nfl, q, tq);
+    p1_quantise<SH>(0, g.fpb * g.C * SLOTS * 16, SLOTS, tb, tb.band_of, g, f0, nfl, q, tq);
 }
 
 template <int LOG2M, int MAXT>
@@ -147,7 +147,7 @@ k_p1_inv(const int32_t* __restrict__ q, const int32_t* __restrict__ tq, double* 
     const int nfl = rem < g.fpb ? (int)rem : g.fpb;
     const int cf = threadIdx.x / TEAM, t = threadIdx.x - cf * TEAM;
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem) + (long long)cf * SLOTS;
-    p1_dequantise<SH>(0, g.fpb * g.C * SLOTS * 16, SLOTS, tb, g, f0, nfl, q, tq);
+    p1_dequantise<SH>(0, g.fpb * g.C * SLOTS * 16, SLOTS, tb, tb.band_of, g, f0, nfl, q, tq);
     __syncthreads();
     dct_pre_inverse<double, LOG2M>(buf, t, post);
     fft_team<double, LOG2M, true>(buf, t, tw);
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) k_p1_fwd_direct(const unsigned char* __re
         X[(long long)c * N + k] = acc * inv_n;
     }
     __syncthreads();
-    p1_quantise<-1>(N * C * 8, 2 * N * C * 8, N, tb, g, f0, 1, q, tq);
+    p1_quantise<-1>(N * C * 8, 2 * N * C * 8, N, tb, tb.band_of, g, f0, 1, q, tq);
 }
 
 template <int UNUSED>
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) k_p1_inv_direct(const int32_t* __restrict
     const long long f0 = blockIdx.x;
     double* X = reinterpret_cast<double*>(smem);
     double* x = X + (long long)N * C;
-    p1_dequantise<-1>(0, 2 * N * C * 8, N, tb, g, f0, 1, q, tq);
+    p1_dequantise<-1>(0, 2 * N * C * 8, N, tb, tb.band_of, g, f0, 1, q, tq);
     __syncthreads();
     const unsigned fourN = 4u * (unsigned)N;
     for (int i = threadIdx.x; i < N * C; i += blockDim.x) {

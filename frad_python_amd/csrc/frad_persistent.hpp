@@ -25,7 +25,7 @@ namespace frad {
 struct PlanA10 { static constexpr int LOG2M = 10, TEAM = 64,  SH = 4, R1 = 16, R2 = 16, R3 = 4, R4 = 0; };  // 2 waves/SIMD
 struct PlanB10 { static constexpr int LOG2M = 10, TEAM = 128, SH = 3, R1 = 8,  R2 = 8,  R3 = 8, R4 = 2; };  // 4 waves/SIMD
 struct PlanI10 { static constexpr int LOG2M = 10, TEAM = 64,  SH = 100, R1 = 4, R2 = 16, R3 = 16, R4 = 0; };  // inverse, fused first pass
-struct PlanA11 { static constexpr int LOG2M = 11, TEAM = 128, SH = 4, R1 = 16, R2 = 16, R3 = 8, R4 = 0; };
+struct PlanA11 { static constexpr int LOG2M = 11, TEAM = 64,  SH = 4, R1 = 16, R2 = 16, R3 = 8, R4 = 0; };
 
 // LDS table blob of a plan (units: complex slots): [pass-2][pass-3][pass-4 tables][w_k][g_k]
 template <typename PL> struct PersLayout {
