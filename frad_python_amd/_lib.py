@@ -27,6 +27,7 @@ SYMBOLS = {
     "frad_plan_clear": (None, []),
     "frad_p0_analogue": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_int32, c_int64, c_int32, c_uint32,
                                  c_void_p, c_int64, c_void_p, c_void_p]),
+    "frad_p0_overflow_scan": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "frad_p0_digital": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_uint32, c_void_p, c_void_p]),
     "frad_p4_analogue": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_int32, c_int64, c_int32, c_uint32,
                                  c_void_p, c_int64, c_void_p, c_void_p]),
@@ -76,6 +77,9 @@ class FradLib:
     def p0_analogue(self, pcm, dtype, n_frames, N, C, frame_stride, bits, flags, payload, payload_stride, absmax, stream=0):
         self._check(self.dll.frad_p0_analogue(pcm, dtype, n_frames, N, C, frame_stride, bits, flags, payload,
                                                payload_stride, absmax, stream))
+
+    def p0_overflow_scan(self, absmax, n_frames, bits, flag, stream=0):
+        self._check(self.dll.frad_p0_overflow_scan(absmax, n_frames, bits, flag, stream))
 
     def p0_digital(self, payload, payload_stride, n_frames, N, C, bits, flags, out, stream=0):
         self._check(self.dll.frad_p0_digital(payload, payload_stride, n_frames, N, C, bits, flags, out, stream))

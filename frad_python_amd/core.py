@@ -111,6 +111,17 @@ def analogue_batch(profile: int, pcm: torch.Tensor, pcm_format: str, n_frames: i
     return EncodedBatch(out, nbytes, bits, absmax, escalated)
 
 
+def overflow_scan(absmax: torch.Tensor, bits: int, flag: torch.Tensor) -> None:
+    """``flag |= any(absmax > FLOAT_MAX[bits])`` in one launch (profile0.py:24-26 over a batch).
+
+    ``flag`` is a device int32 scalar kept across batches; read it when the answer is needed."""
+    _require_cuda(absmax, "absmax"); _require_cuda(flag, "flag")
+    if absmax.dtype != torch.float64 or flag.dtype != torch.int32:
+        raise TypeError("absmax must be float64 and flag int32")
+    with torch.cuda.device(absmax.device):
+        _lib.load().p0_overflow_scan(absmax.data_ptr(), absmax.numel(), bits, flag.data_ptr(), _stream_ptr())
+
+
 def digital_batch(profile: int, payload: torch.Tensor, n_frames: int, N: int, C: int, bits: int,
                   little_endian: bool = False, *, payload_stride: int | None = None,
                   out: torch.Tensor | None = None) -> torch.Tensor:

@@ -309,6 +309,18 @@ int frad_p4_digital(const void* payload, int64_t payload_stride, int64_t n_frame
     return FRAD_OK;
 }
 
+int frad_p0_overflow_scan(const double* absmax, int64_t n_frames, int32_t bits, int32_t* flag, void* stream) {
+    if (n_frames < 0 || !valid_bits(bits)) return FRAD_E_INVALID;
+    if (n_frames == 0) return FRAD_OK;
+    if (!absmax || !flag) return FRAD_E_INVALID;
+    const double lim = bits <= 16 ? 65504.0 : bits <= 32 ? 3.4028234663852886e38 : 1.7976931348623157e308;   // FLOAT_DR, profile0.py:6-13
+    long long blocks = (n_frames + 1023) / 1024;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(k_overflow_scan<0>, dim3((unsigned)blocks), dim3(1024), 0, static_cast<hipStream_t>(stream), absmax, (long long)n_frames, lim, flag);
+    HIPCHK(hipGetLastError());
+    return FRAD_OK;
+}
+
 int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C, int64_t frame_stride,
                      int32_t bits, uint32_t flags, void* payload, int64_t payload_stride, double* absmax, void* stream) {
     int rc = check_common(pcm, payload, n_frames, N, C, bits);

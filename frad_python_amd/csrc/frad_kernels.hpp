@@ -818,6 +818,15 @@ __global__ void __launch_bounds__(MAXT) k_p0_inv_grp(const unsigned char* __rest
     }
 }
 
+// absmax[i] > lim for any i -> *flag |= 1 (profile0.py:24-26 as one batch test; NaN compares false)
+template <int DUMMY>
+__global__ void __launch_bounds__(1024) k_overflow_scan(const double* __restrict__ absmax, long long n, double lim, int* flag) {
+    bool over = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        over |= absmax[i] > lim;
+    if (over) atomicOr(flag, 1);
+}
+
 // =============================================================================================
 // direct kernels: any N.  cos table ct[j] = cos(pi * j / (2N)), j in [0, 4N).
 // LDS: x (T) and X (T) per channel-frame, plain arrays of N reals each.

@@ -85,6 +85,12 @@ int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
                      int64_t frame_stride, int32_t bits, uint32_t flags,
                      void* payload, int64_t payload_stride, double* absmax, void* stream);
 
+/* The overflow test of profile0.py:24-26 over a batch, on the device: *flag |= 1 if any absmax[i] is
+ * greater than the largest finite value of the `bits` storage float (NaN never is, like numpy's
+ * comparison).  `flag` is a device int32 the caller zeroes once and reads when it needs the answer
+ * (sticky across calls), so a steady stream of batches needs no host round trip per batch.        */
+int frad_p0_overflow_scan(const double* absmax, int64_t n_frames, int32_t bits, int32_t* flag, void* stream);
+
 /* frad_p0_digital == fourier.profile0.digital (profile0.py:46-69): unpack, NaN/Inf -> 0, inverse
  * DCT in float64, [N, C] interleaved float64 out (frame i at pcm_out + i*N*C).                    */
 int frad_p0_digital(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C,

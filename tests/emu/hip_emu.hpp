@@ -93,6 +93,8 @@ inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v)
     return old;
 }
 
+inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+
 inline long long __double_as_longlong(double d) { long long r; std::memcpy(&r, &d, 8); return r; }
 inline double __longlong_as_double(long long v) { double r; std::memcpy(&r, &v, 8); return r; }
 inline uint32_t __float_as_uint(float f) { uint32_t r; std::memcpy(&r, &f, 4); return r; }

@@ -62,6 +62,11 @@ class EmuBackend:
         fn(buf.ctypes.data + offset, stride, F, N, C, bits, int(le), out.ctypes.data)
         return out[:F]
 
+    def overflow_scan(self, absmax, bits, flag0=0):
+        am = np.ascontiguousarray(absmax, np.float64)
+        flag = np.array([flag0], np.int32)
+        self.lib.p0_overflow_scan(am.ctypes.data, am.size, bits, flag.ctypes.data)
+        return int(flag[0])
 
     # ---- profile 1 ----
     def p1_analogue(self, raw, fmt, F, N, C, bits, srate, loss, frame_stride=None, n_valid=None):
@@ -126,6 +131,15 @@ class GpuBackend:
         out = core.digital_batch(profile, view, F, N, C, bits, le, payload_stride=stride)
         t.cuda.synchronize()
         return out.cpu().numpy()
+
+    def overflow_scan(self, absmax, bits, flag0=0):
+        from frad_python_amd import core
+        t = self.torch
+        am = t.from_numpy(np.ascontiguousarray(absmax, np.float64)).to(self.dev)
+        flag = t.full((), flag0, dtype=t.int32, device=self.dev)
+        core.overflow_scan(am, bits, flag)
+        t.cuda.synchronize()
+        return int(flag.item())
 
     # ---- profile 1 ----
     def p1_analogue(self, raw, fmt, F, N, C, bits, srate, loss, frame_stride=None, n_valid=None):

@@ -192,6 +192,23 @@ def test_nan_inf_scrub_and_absmax_semantics(be, g5):
     assert am[0] == np.inf
 
 
+def test_overflow_scan_matches_escalation_rule(be):
+    """frad_p0_overflow_scan == any(absmax > FLOAT_DR max), the loop condition of profile0.py:24-26"""
+    from frad_python_amd.core import FLOAT_MAX
+    rng = np.random.default_rng(5)
+    base = rng.uniform(0, 60000, 5000)
+    for bits in (12, 16, 24, 32, 48, 64):
+        lim = FLOAT_MAX[bits]
+        assert be.overflow_scan(base if bits <= 16 else base * 1e30, bits) == 0
+        for pos in (0, 1023, 1024, 4999):
+            am = base.copy(); am[pos] = np.inf if bits >= 48 else np.nextafter(lim, np.inf)
+            assert be.overflow_scan(am, bits) == 1
+        am = base.copy(); am[7] = lim; am[9] = np.nan          # equal to the limit or NaN: no escalation
+        assert be.overflow_scan(am, bits) == 0
+        assert be.overflow_scan(base, bits, flag0=1) == 1        # sticky
+    assert be.overflow_scan(np.zeros(0), 32) == 0
+
+
 def test_empty_batch(be):
     pay, am = be.analogue(0, np.zeros(0, np.int16), "s16le", 0, 2048, 2, 32, False)
     assert pay.shape[0] == 0

@@ -7,7 +7,7 @@ TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+BENCH="python3 $R/bench.py --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_trace -- $BENCH > $R/gpurun_out/prof_${TAG}_trace.log 2>&1 || exit 1
 SHORT="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_${TAG}_fetch -- $SHORT > $R/gpurun_out/prof_${TAG}_fetch.log 2>&1 || exit 1
