@@ -348,12 +348,39 @@ __device__ __forceinline__ uint32_t payload_byte(int64_t s, int bits, bool le, i
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 abs_bits(double v) { return d2u(v) & 0x7fffffffffffffffULL; }
 
-__device__ __forceinline__ u64 wave_max_u64(u64 v) {
-    for (int off = 32; off > 0; off >>= 1) {
-        u64 o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
+// Wave-wide butterfly all-reduce (xor 1, 2, 4, 8, 16, 32) of a 64-bit value.  On gfx950 the first four steps are DPP
+// moves -- quad_perm for xor 1 / 2, row_half_mirror and row_mirror for xor 4 / 8 (their partners hold the same value as
+// the xor partners once the smaller groups are uniform) -- and the last two read one lane per 16-lane row through
+// SGPRs, so no step goes through the LDS crossbar (a ds_bpermute pair per step otherwise).  The emulator runs the
+// plain xor butterfly; both combine the same operands in the same order.
+#ifndef FRAD_HOST_EMULATION
+template <int CTRL> __device__ __forceinline__ u64 dpp_move_u64(u64 v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, false);
+    return (u64)(uint32_t)lo | ((u64)(uint32_t)hi << 32);
+}
+__device__ __forceinline__ u64 read_lane_u64(u64 v, int lane) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return (u64)lo | ((u64)hi << 32);
+}
+#endif
+template <class Op> __device__ __forceinline__ u64 wave_allreduce_u64(u64 v, Op op) {
+#ifdef FRAD_HOST_EMULATION
+    for (int off = 1; off < 64; off <<= 1) v = op(v, __shfl_xor(v, off, 64));
     return v;
+#else
+    v = op(v, dpp_move_u64<0xB1>(v));                        // quad_perm [1,0,3,2]
+    v = op(v, dpp_move_u64<0x4E>(v));                        // quad_perm [2,3,0,1]
+    v = op(v, dpp_move_u64<0x141>(v));                       // row_half_mirror
+    v = op(v, dpp_move_u64<0x140>(v));                       // row_mirror
+    const u64 r0 = read_lane_u64(v, 0), r1 = read_lane_u64(v, 16), r2 = read_lane_u64(v, 32), r3 = read_lane_u64(v, 48);
+    return op(op(r0, r1), op(r2, r3));
+#endif
+}
+
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+    return wave_allreduce_u64(v, [](u64 a, u64 b) { return b > a ? b : a; });
 }
 
 }  // namespace frad

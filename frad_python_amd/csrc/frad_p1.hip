@@ -132,10 +132,10 @@ int frad_p1_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
     FastCfg c = fast_cfg(N, C, false);
     if (c.ok && c.cg == C) {
         const int M = 1 << c.log2m;
-        while (c.fpb > 1 && (size_t)c.fpb * C * (M * 16 + P1_BANDS * 8) > 80 * 1024) { c.fpb -= 1; }
+        while (c.fpb > 1 && (size_t)c.fpb * C * M * 16 + p1_scratch_bytes(c.fpb * C, N) > 80 * 1024) { c.fpb -= 1; }
         c.threads = c.fpb * C * c.team;
         if (c.threads > 1024 || c.threads % 64) return FRAD_E_UNSUPPORTED;
-        const size_t lds = (size_t)c.fpb * C * (M * 16 + P1_BANDS * 8);
+        const size_t lds = (size_t)c.fpb * C * M * 16 + p1_scratch_bytes(c.fpb * C, N);
         if (lds > kLds) return FRAD_E_UNSUPPORTED;
         Tables t; rc = get_tables(c.log2m, false, t);
         if (rc != FRAD_OK) return rc;
@@ -152,7 +152,7 @@ int frad_p1_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
             default: go_fwd<13>(lg, c, lds, grid, s, in, q, tq, t, g, tb, ai); break;
         }
     } else {
-        const size_t lds = 2 * (size_t)N * C * 8 + (size_t)P1_BANDS * C * 8;
+        const size_t lds = 2 * (size_t)N * C * 8 + p1_scratch_bytes(C, N);
         if (lds > kLds || n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
         DirectTable d; rc = get_direct(N, d);
         if (rc != FRAD_OK) return rc;
@@ -178,10 +178,10 @@ int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32
     FastCfg c = fast_cfg(N, C, false);
     if (c.ok && c.cg == C) {
         const int M = 1 << c.log2m;
-        while (c.fpb > 1 && (size_t)c.fpb * C * (M * 16 + P1_BANDS * 8) > 80 * 1024) { c.fpb -= 1; }
+        while (c.fpb > 1 && (size_t)c.fpb * C * M * 16 + p1_scratch_bytes(c.fpb * C, N) > 80 * 1024) { c.fpb -= 1; }
         c.threads = c.fpb * C * c.team;
         if (c.threads > 1024 || c.threads % 64) return FRAD_E_UNSUPPORTED;
-        const size_t lds = (size_t)c.fpb * C * (M * 16 + P1_BANDS * 8);
+        const size_t lds = (size_t)c.fpb * C * M * 16 + p1_scratch_bytes(c.fpb * C, N);
         if (lds > kLds) return FRAD_E_UNSUPPORTED;
         Tables t; rc = get_tables(c.log2m, false, t);
         if (rc != FRAD_OK) return rc;
@@ -198,7 +198,7 @@ int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32
             default: go_inv<13>(c, lds, grid, s, q, tq, pcm_out, t, g, tb); break;
         }
     } else {
-        const size_t lds = 2 * (size_t)N * C * 8 + (size_t)P1_BANDS * C * 8;
+        const size_t lds = 2 * (size_t)N * C * 8 + p1_scratch_bytes(C, N);
         if (lds > kLds || n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
         DirectTable d; rc = get_direct(N, d);
         if (rc != FRAD_OK) return rc;

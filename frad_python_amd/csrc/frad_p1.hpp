@@ -26,8 +26,7 @@ struct P1Tables {
 };
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
-    for (int off = 32; off > 0; off >>= 1) v += u2d(__shfl_xor(d2u(v), off, 64));
-    return v;
+    return u2d(wave_allreduce_u64(d2u(v), [](u64 a, u64 b) { return d2u(u2d(a) + u2d(b)); }));
 }
 
 // |x|^0.75 with sign (p1tools.py:43) and its inverse |x|^(1/0.75) (p1tools.py:44).  a^0.75 = sqrt(a) * sqrt(sqrt(a)):
@@ -37,83 +36,136 @@ __device__ __forceinline__ double p1_quant(double x) {
     const double a = fabs(x), r = sqrt(a);
     return copysign(r * sqrt(r), x) * (a != 0.0);
 }
-__device__ __forceinline__ double p1_dequant(double x) { const double a = fabs(x); return copysign(pow(a, 1.0 / 0.75), x) * (a != 0.0); }
+// |x|^(4/3) = |x| * cbrt(|x|) (the reference raises to 1/0.75, whose double differs from 4/3 by 2^-54 relative: far
+// below the 1e-9 the decode contract states)
+__device__ __forceinline__ double p1_dequant(double x) { const double a = fabs(x); return copysign(a * cbrt(a), x) * (a != 0.0); }
 
-// linear ramp between consecutive band starts, endpoint excluded (np.linspace as mapping_from_opus
-// uses it, p1tools.py:35-41); bins beyond the last start map to 0.
-__device__ __forceinline__ double p1_spread(const double* thres, const int* edge, const unsigned char* band_of, int N, int k) {
-    const int j = band_of[k];                             // host-built: start_j <= k < start_{j+1}, starts clipped to N
-    if (j >= P1_BANDS - 1) return 0.0;
-    const int a = edge[j] < N ? edge[j] : N, e = edge[j + 1] < N ? edge[j + 1] : N;
-    const double start = thres[j], delta = thres[j + 1] - start, num = (double)(e - a);
-    const double step = delta / num;
-    const double i = (double)(k - a);
-    const double y = (step == 0.0) ? (i / num) * delta : i * step;       // numpy's denormal-safe branch
-    return y + start;
+// LDS scratch of the quantiser stages, after the transform buffers:
+//   thres[cf][27] | step[cf][27] | floor[28] (doubles) | edge[32] (ints, clipped to N) | band_of[N] (bytes)
+// The per-launch tables arrive as kernel arguments; p1_tables_to_lds copies them once per block so that the
+// data-dependent lookups below are LDS reads (a by-value struct indexed at run time lives in scratch memory).
+__host__ __device__ constexpr int p1_scratch_bytes(int cfs, int N) { return cfs * P1_BANDS * 16 + 28 * 8 + 32 * 4 + ((N + 15) / 16) * 16; }
+
+struct P1Lds {
+    double* thres; double* step; double* floor_; int* edge; unsigned char* band;
+};
+__device__ __forceinline__ P1Lds p1_lds(unsigned char* scratch, int cfs) {
+    P1Lds l;
+    l.thres = reinterpret_cast<double*>(scratch);
+    l.step = l.thres + cfs * P1_BANDS;
+    l.floor_ = l.step + cfs * P1_BANDS;
+    l.edge = reinterpret_cast<int*>(l.floor_ + 28);
+    l.band = reinterpret_cast<unsigned char*>(l.edge + 32);
+    return l;
+}
+__device__ __forceinline__ void p1_tables_to_lds(unsigned char* scratch, int cfs, const P1Tables& tb, int N) {
+    const P1Lds l = p1_lds(scratch, cfs);
+    if (threadIdx.x <= P1_BANDS) l.edge[threadIdx.x] = tb.edge[threadIdx.x] < N ? tb.edge[threadIdx.x] : N;
+    if (threadIdx.x < P1_BANDS) l.floor_[threadIdx.x] = tb.floor_[threadIdx.x];
+    if ((N & 3) == 0) {
+        for (int i = threadIdx.x; i < N / 4; i += blockDim.x)
+            reinterpret_cast<uint32_t*>(l.band)[i] = reinterpret_cast<const uint32_t*>(tb.band_of)[i];
+    } else {
+        for (int i = threadIdx.x; i < N; i += blockDim.x) l.band[i] = tb.band_of[i];
+    }
 }
 
-// K7 epilogue: X[k] of `nfl` frames x C channels sit in LDS (xslot<double, SH>); scratch = 27*C*nfl doubles.
+// linear ramp between consecutive band starts, endpoint excluded (np.linspace as mapping_from_opus uses it,
+// p1tools.py:35-41): y = start_j + i * step_j with step_j = (thres[j+1] - thres[j]) / (bins in band j), computed once
+// per band; bins beyond the last start map to 0.
+__device__ __forceinline__ void p1_ramp_steps(const P1Lds& l, int cfs) {
+    for (int i = threadIdx.x; i < cfs * P1_BANDS; i += blockDim.x) {
+        const int j = i % P1_BANDS;
+        double st = 0.0;
+        if (j < P1_BANDS - 1) {
+            const int num = l.edge[j + 1] - l.edge[j];
+            if (num > 0) st = (l.thres[i + 1] - l.thres[i]) / (double)num;
+        }
+        l.step[i] = st;
+    }
+}
+__device__ __forceinline__ double p1_spread(const P1Lds& l, int cf, int k) {
+    const int j = l.band[k];
+    if (j >= P1_BANDS - 1) return 0.0;
+    const double* thres = l.thres + cf * P1_BANDS;
+    const int a = l.edge[j];
+    const double i = (double)(k - a), st = l.step[cf * P1_BANDS + j];
+    double y = i * st;
+    if (st == 0.0) y = (i / (double)(l.edge[j + 1] - a)) * (thres[j + 1] - thres[j]);    // numpy's denormal-safe branch
+    return y + thres[j];
+}
+
+// K7 epilogue: X[k] of `nfl` frames x C channels sit in LDS (xslot<double, SH>); scratch as above for fpb * C slots.
 template <int SH>
-__device__ FRAD_NOINLINE void p1_quantise(int smem_off, int scratch_off, int slots, const P1Tables tb, const unsigned char* __restrict__ band_of, const Geom& g,
+__device__ FRAD_NOINLINE void p1_quantise(int smem_off, int scratch_off, int slots, double scale, double loss, int nb_used, const Geom& g,
                                           long long f0, int nfl, int32_t* __restrict__ q, int32_t* __restrict__ tq) {
     FRAD_DYN_SMEM(base);
     unsigned char* smem = base + smem_off;
-    double* thres = reinterpret_cast<double*>(base + scratch_off);
     const int N = g.N, C = g.C, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const P1Lds l = p1_lds(base + scratch_off, g.fpb * C);
     // band energies: one (frame, channel, band) task per wave
     for (int task = wave; task < nfl * C * P1_BANDS; task += nwaves) {
         const int b = task % P1_BANDS, cf = task / P1_BANDS;
-        const int a = tb.edge[b] < N ? tb.edge[b] : N, e = tb.edge[b + 1] < N ? tb.edge[b + 1] : N;
+        const int a = l.edge[b], e = l.edge[b + 1];
         double acc = 0.0;
-        for (int k = a + lane; k < e; k += 64) { const double v = xslot<double, SH>(smem, cf, slots, k) * tb.scale; acc = fma(v, v, acc); }
+        for (int k = a + lane; k < e; k += 64) { const double v = xslot<double, SH>(smem, cf, slots, k) * scale; acc = fma(v, v, acc); }
         acc = wave_sum_f64(acc);
-        if (lane == 0) {
-            double t = 0.0;
-            if (b < tb.nb_used) {
-                const double sfq = pow(sqrt(acc / (double)(e - a)), 0.8);
-                t = (sfq > tb.floor_[b] ? sfq : tb.floor_[b]) * tb.loss;
-            }
-            thres[cf * P1_BANDS + b] = t;
-        }
+        if (lane == 0) l.thres[cf * P1_BANDS + b] = acc;
     }
     __syncthreads();
+    // energies -> thresholds, one entry per thread (p1tools.py:18-33)
+    for (int i = threadIdx.x; i < nfl * C * P1_BANDS; i += blockDim.x) {
+        const int b = i % P1_BANDS;
+        double t = 0.0;
+        if (b < nb_used) {
+            const double sfq = pow(sqrt(l.thres[i] / (double)(l.edge[b + 1] - l.edge[b])), 0.8);
+            t = (sfq > l.floor_[b] ? sfq : l.floor_[b]) * loss;
+        }
+        l.thres[i] = t;
+    }
+    __syncthreads();
+    p1_ramp_steps(l, nfl * C);
     // quantised thresholds, band-major / channel-minor
     for (int i = threadIdx.x; i < nfl * P1_BANDS * C; i += blockDim.x) {
         const int fl = i / (P1_BANDS * C), r = i - fl * P1_BANDS * C, b = r / C, c = r - b * C;
-        const double t = thres[(fl * C + c) * P1_BANDS + b];
+        const double t = l.thres[(fl * C + c) * P1_BANDS + b];
         const double v = log(t > 1.0 ? t : 1.0) / log(2.718281828459045 / 2);
-        tq[(f0 + fl) * (long long)(P1_BANDS * C) + r] = (int32_t)rint(p1_dequant(v));
+        tq[(f0 + fl) * (long long)(P1_BANDS * C) + r] = (int32_t)rint(copysign(pow(fabs(v), 1.0 / 0.75), v));
     }
+    __syncthreads();
     // per-bin divide + power-law quantiser, bin-major / channel-minor
     const int NC = N * C;
     for (int i = threadIdx.x; i < nfl * NC; i += blockDim.x) {
-        const int fl = i / NC, r = i - fl * NC, k = r / C, c = r - k * C;
-        const double x = xslot<double, SH>(smem, fl * C + c, slots, k);
-        const double div = p1_spread(thres + (fl * C + c) * P1_BANDS, tb.edge, band_of, N, k);
+        const int fl = i / NC, r = i - fl * NC, k = r / C, c = r - k * C, cf = fl * C + c;
+        const double x = xslot<double, SH>(smem, cf, slots, k);
+        const double div = p1_spread(l, cf, k);
         const double m = (div == 0.0) ? 0.0 * x : x / div;                // x / inf keeps the sign of x
-        q[(f0 + fl) * (long long)NC + r] = (int32_t)rint(p1_quant(m * tb.scale));
+        q[(f0 + fl) * (long long)NC + r] = (int32_t)rint(p1_quant(m * scale));
     }
 }
 
 // K8 prologue: q / tq -> X[k] in LDS.
 template <int SH>
-__device__ FRAD_NOINLINE void p1_dequantise(int smem_off, int scratch_off, int slots, const P1Tables tb, const unsigned char* __restrict__ band_of, const Geom& g,
+__device__ FRAD_NOINLINE void p1_dequantise(int smem_off, int scratch_off, int slots, double scale, const Geom& g,
                                             long long f0, int nfl, const int32_t* __restrict__ q, const int32_t* __restrict__ tq) {
     FRAD_DYN_SMEM(base);
     unsigned char* smem = base + smem_off;
-    double* thres = reinterpret_cast<double*>(base + scratch_off);
     const int N = g.N, C = g.C;
+    const P1Lds l = p1_lds(base + scratch_off, g.fpb * C);
     for (int i = threadIdx.x; i < nfl * P1_BANDS * C; i += blockDim.x) {
         const int fl = i / (P1_BANDS * C), r = i - fl * P1_BANDS * C, b = r / C, c = r - b * C;
         const double t = (double)tq[(f0 + fl) * (long long)(P1_BANDS * C) + r];
-        thres[(fl * C + c) * P1_BANDS + b] = pow(2.718281828459045 / 2, p1_quant(t));
+        l.thres[(fl * C + c) * P1_BANDS + b] = pow(2.718281828459045 / 2, p1_quant(t));
     }
+    __syncthreads();                                         // also orders p1_tables_to_lds (kernel start) before its readers
+    p1_ramp_steps(l, nfl * C);
     __syncthreads();
     const int NC = N * C;
+    const double inv_scale = scale;
     for (int i = threadIdx.x; i < nfl * NC; i += blockDim.x) {
-        const int fl = i / NC, r = i - fl * NC, k = r / C, c = r - k * C;
-        const double v = p1_dequant((double)q[(f0 + fl) * (long long)NC + r]) / tb.scale;
-        xslot<double, SH>(smem, fl * C + c, slots, k) = v * p1_spread(thres + (fl * C + c) * P1_BANDS, tb.edge, band_of, N, k);
+        const int fl = i / NC, r = i - fl * NC, k = r / C, c = r - k * C, cf = fl * C + c;
+        const double v = p1_dequant((double)q[(f0 + fl) * (long long)NC + r]) / inv_scale;
+        xslot<double, SH>(smem, cf, slots, k) = v * p1_spread(l, cf, k);
     }
 }
 
@@ -128,12 +180,13 @@ k_p1_fwd(const unsigned char* __restrict__ pcm, int32_t* __restrict__ q, int32_t
     const int nfl = rem < g.fpb ? (int)rem : g.fpb;
     const int cf = threadIdx.x / TEAM, t = threadIdx.x - cf * TEAM;
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem) + (long long)cf * SLOTS;
+    p1_tables_to_lds(smem + g.fpb * g.C * SLOTS * 16, g.fpb * g.C, tb, g.N);
     stage_in_pcm<double, LG, SH, true>(pcm, 0, g, f0, nfl, SLOTS, aligned_in != 0);
     __syncthreads();
     fft_team<double, LOG2M, false>(buf, t, tw);
     dct_post<double, LOG2M>(buf, t, post);
     __syncthreads();
-    p1_quantise<SH>(0, g.fpb * g.C * SLOTS * 16, SLOTS, tb, tb.band_of, g, f0, nfl, q, tq);
+    p1_quantise<SH>(0, g.fpb * g.C * SLOTS * 16, SLOTS, tb.scale, tb.loss, tb.nb_used, g, f0, nfl, q, tq);
 }
 
 template <int LOG2M, int MAXT>
@@ -147,7 +200,8 @@ k_p1_inv(const int32_t* __restrict__ q, const int32_t* __restrict__ tq, double* 
     const int nfl = rem < g.fpb ? (int)rem : g.fpb;
     const int cf = threadIdx.x / TEAM, t = threadIdx.x - cf * TEAM;
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem) + (long long)cf * SLOTS;
-    p1_dequantise<SH>(0, g.fpb * g.C * SLOTS * 16, SLOTS, tb, tb.band_of, g, f0, nfl, q, tq);
+    p1_tables_to_lds(smem + g.fpb * g.C * SLOTS * 16, g.fpb * g.C, tb, g.N);
+    p1_dequantise<SH>(0, g.fpb * g.C * SLOTS * 16, SLOTS, tb.scale, g, f0, nfl, q, tq);
     __syncthreads();
     dct_pre_inverse<double, LOG2M>(buf, t, post);
     fft_team<double, LOG2M, true>(buf, t, tw);
@@ -164,6 +218,7 @@ __global__ void __launch_bounds__(256) k_p1_fwd_direct(const unsigned char* __re
     const long long f0 = blockIdx.x;
     double* x = reinterpret_cast<double*>(smem);
     double* X = x + (long long)N * C;
+    p1_tables_to_lds(smem + 2 * N * C * 8, C, tb, N);
     stage_in_pcm<double, LG, -1, false>(pcm, 0, g, f0, 1, N, aligned_in != 0);
     __syncthreads();
     const double inv_n = 1.0 / (double)N;
@@ -178,7 +233,7 @@ __global__ void __launch_bounds__(256) k_p1_fwd_direct(const unsigned char* __re
         X[(long long)c * N + k] = acc * inv_n;
     }
     __syncthreads();
-    p1_quantise<-1>(N * C * 8, 2 * N * C * 8, N, tb, tb.band_of, g, f0, 1, q, tq);
+    p1_quantise<-1>(N * C * 8, 2 * N * C * 8, N, tb.scale, tb.loss, tb.nb_used, g, f0, 1, q, tq);
 }
 
 template <int UNUSED>
@@ -189,7 +244,8 @@ __global__ void __launch_bounds__(256) k_p1_inv_direct(const int32_t* __restrict
     const long long f0 = blockIdx.x;
     double* X = reinterpret_cast<double*>(smem);
     double* x = X + (long long)N * C;
-    p1_dequantise<-1>(0, 2 * N * C * 8, N, tb, tb.band_of, g, f0, 1, q, tq);
+    p1_tables_to_lds(smem + 2 * N * C * 8, C, tb, N);
+    p1_dequantise<-1>(0, 2 * N * C * 8, N, tb.scale, g, f0, 1, q, tq);
     __syncthreads();
     const unsigned fourN = 4u * (unsigned)N;
     for (int i = threadIdx.x; i < N * C; i += blockDim.x) {
