@@ -169,6 +169,20 @@ int check_common(const void* a, const void* b, long long n_frames, int N, int C,
     return FRAD_OK;
 }
 
+// direct (any-N) kernels: frames per block so that a thread's table fetch feeds up to 8 channel-frames, but
+// never so many that CUs stay idle or the staging buffers outgrow the LDS; one thread per output index
+int direct_fpb(long long n_frames, int C, size_t per_frame_lds) {
+    long long fpb = C >= 8 ? 1 : 8 / C;
+    const long long spread = n_frames / 256;                  // keep >= one block per CU when the batch allows
+    if (fpb > spread) fpb = spread < 1 ? 1 : spread;
+    while (fpb > 1 && (size_t)fpb * per_frame_lds > (size_t)kLdsBytes) --fpb;
+    return (int)fpb;
+}
+int direct_threads(int N) {
+    const int t = ((N + 63) / 64) * 64;
+    return t > 1024 ? 1024 : t;
+}
+
 int blocks_per_frame(long long work_items) {
     long long b = (work_items + 255) / 256;
     return (int)(b < 1 ? 1 : b > 64 ? 64 : b);
@@ -233,6 +247,7 @@ int frad_plan_prepare(int32_t N, int32_t compute_f32) {
     const int l2 = log2_exact(N);
     if (l2 >= 7 && l2 <= 14) { Tables t; return get_tables(l2 - 1, compute_f32 != 0, t); }
     if (N < 1) return FRAD_E_INVALID;
+    if (!compute_f32) { const int rc = blue_prepare(N); if (rc != FRAD_OK) return rc; }
     DirectTable d; return get_direct(N, d);
 }
 
@@ -241,6 +256,7 @@ void frad_plan_clear(void) {
     for (auto& kv : g_tables) { (void)hipFree(kv.second.tw); (void)hipFree(kv.second.post); if (kv.second.blob) (void)hipFree(kv.second.blob); if (kv.second.blob_b) (void)hipFree(kv.second.blob_b); if (kv.second.blob_i) (void)hipFree(kv.second.blob_i); }
     for (auto& kv : g_direct) (void)hipFree(kv.second.ct);
     g_tables.clear(); g_direct.clear();
+    blue_clear();
 }
 
 int frad_p4_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C, int64_t frame_stride,
@@ -355,14 +371,24 @@ int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
             if (rc != FRAD_OK) return rc;
         }
     } else {
-        const size_t lds = 2 * (size_t)N * C * (f32 ? 4 : 8);
-        if (lds > (size_t)kLdsBytes || n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
+        if (!f32) {                                          // any N in O(N log N): Bluestein over the power-of-two FFT
+            const int r = launch_p0_fwd_blue(lg, s, in, out, absmax, g, ao);
+            if (r < 0) { if (r == FRAD_E_HIP) g_last_hip = blue_last_hip_error(); return r; }
+            if (r == 1) { HIPCHK(hipGetLastError()); return FRAD_OK; }
+        }
+        const size_t per_frame = 2 * (size_t)N * C * (f32 ? 4 : 8);
+        if (per_frame > (size_t)kLdsBytes) return FRAD_E_UNSUPPORTED;
         DirectTable d; rc = get_direct(N, d);
         if (rc != FRAD_OK) return rc;
         if (absmax) HIPCHK(hipMemsetAsync(absmax, 0, sizeof(double) * (size_t)n_frames, s));
-        dim3 grid((unsigned)n_frames);
+        g.fpb = direct_fpb(n_frames, C, per_frame);
+        const size_t lds = per_frame * (size_t)g.fpb;
+        const long long nblk = (n_frames + g.fpb - 1) / g.fpb;
+        if (nblk > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
+        dim3 grid((unsigned)nblk);
+        const dim3 blk((unsigned)direct_threads(N));
 #define FRAD_DIR(TT, LGV) do { allow_lds(k_p0_fwd_direct<TT, LGV>, lds); \
-        hipLaunchKernelGGL((k_p0_fwd_direct<TT, LGV>), grid, dim3(256), lds, s, in, out, absmax, d.ct, g, ai, ao); } while (0)
+        hipLaunchKernelGGL((k_p0_fwd_direct<TT, LGV>), grid, blk, lds, s, in, out, absmax, d.ct, g, ai, ao); } while (0)
         if (f32) { if (lg == 1) FRAD_DIR(float, 1); else FRAD_DIR(float, 2); }
         else switch (lg) { case 0: FRAD_DIR(double, 0); break; case 1: FRAD_DIR(double, 1); break; case 2: FRAD_DIR(double, 2); break; default: FRAD_DIR(double, 3); break; }
 #undef FRAD_DIR
@@ -395,12 +421,19 @@ int frad_p0_digital(const void* payload, int64_t payload_stride, int64_t n_frame
             if (rc != FRAD_OK) return rc;
         }
     } else {
-        const size_t lds = 2 * (size_t)N * C * 8;
-        if (lds > (size_t)kLdsBytes || n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
+        const int r = launch_p0_inv_blue(s, in, pcm_out, g, ai);
+        if (r < 0) { if (r == FRAD_E_HIP) g_last_hip = blue_last_hip_error(); return r; }
+        if (r == 1) { HIPCHK(hipGetLastError()); return FRAD_OK; }
+        const size_t per_frame = 2 * (size_t)N * C * 8;
+        if (per_frame > (size_t)kLdsBytes) return FRAD_E_UNSUPPORTED;
         DirectTable d; rc = get_direct(N, d);
         if (rc != FRAD_OK) return rc;
+        g.fpb = direct_fpb(n_frames, C, per_frame);
+        const size_t lds = per_frame * (size_t)g.fpb;
+        const long long nblk = (n_frames + g.fpb - 1) / g.fpb;
+        if (nblk > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
         allow_lds(k_p0_inv_direct<0>, lds);
-        hipLaunchKernelGGL(k_p0_inv_direct<0>, dim3((unsigned)n_frames), dim3(256), lds, s, in, pcm_out, d.ct, g, ai);
+        hipLaunchKernelGGL(k_p0_inv_direct<0>, dim3((unsigned)nblk), dim3((unsigned)direct_threads(N)), lds, s, in, pcm_out, d.ct, g, ai);
     }
     HIPCHK(hipGetLastError());
     return FRAD_OK;

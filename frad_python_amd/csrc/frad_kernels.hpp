@@ -831,60 +831,83 @@ __global__ void __launch_bounds__(1024) k_overflow_scan(const double* __restrict
 // direct kernels: any N.  cos table ct[j] = cos(pi * j / (2N)), j in [0, 4N).
 // LDS: x (T) and X (T) per channel-frame, plain arrays of N reals each.
 // =============================================================================================
+// Both are a dense cosine product, so the work is tiled like one: a thread owns one output index and up
+// to 8 channel-frames (columns) at a time, so a table value fetched for (k, n) feeds 8 FMAs and the LDS
+// operand reads are wave-wide broadcasts.  g.fpb frames per block (host: 8 / C, fewer when that would leave CUs idle).
+template <typename T, bool FWD>
+__device__ __forceinline__ void direct_product(const T* __restrict__ src, T* __restrict__ dst, const double* __restrict__ ct,
+                                               int N, int cols) {
+    const unsigned fourN = 4u * (unsigned)N;
+    const double inv_n = 1.0 / (double)N;
+    for (int o = threadIdx.x; o < N; o += blockDim.x) {
+        // forward: o = k, table index k (2n + 1) mod 4N over n;  inverse: o = n, same index over k >= 1
+        const unsigned step = FWD ? (2u * (unsigned)o) % fourN : (2u * (unsigned)o + 1u) % fourN;
+        for (int c0 = 0; c0 < cols; c0 += 8) {
+            const int nb = cols - c0 < 8 ? cols - c0 : 8;
+            const T* sb = src + (long long)c0 * N;
+            double acc[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[b] = 0.0;
+            unsigned jj = FWD ? (unsigned)o % fourN : step;
+            if (nb == 8) {
+#pragma unroll 4
+                for (int i = FWD ? 0 : 1; i < N; ++i) {
+                    const double w = ct[jj];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) acc[b] = fma((double)sb[(long long)b * N + i], w, acc[b]);
+                    jj += step; if (jj >= fourN) jj -= fourN;
+                }
+            } else {
+#pragma unroll 2
+                for (int i = FWD ? 0 : 1; i < N; ++i) {
+                    const double w = ct[jj];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) if (b < nb) acc[b] = fma((double)sb[(long long)b * N + i], w, acc[b]);
+                    jj += step; if (jj >= fourN) jj -= fourN;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) if (b < nb) {
+                if constexpr (FWD) dst[(long long)(c0 + b) * N + o] = (T)(acc[b] * inv_n);
+                else dst[(long long)(c0 + b) * N + o] = (T)((double)sb[(long long)b * N] + 2.0 * acc[b]);
+            }
+        }
+    }
+}
+
 template <typename T, int LG>
-__global__ void __launch_bounds__(256) k_p0_fwd_direct(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload,
-                                                       double* absmax, const double* __restrict__ ct, Geom g,
-                                                       int aligned_in, int aligned_out) {
+__global__ void __launch_bounds__(1024) k_p0_fwd_direct(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload,
+                                                        double* absmax, const double* __restrict__ ct, Geom g,
+                                                        int aligned_in, int aligned_out) {
     FRAD_DYN_SMEM(smem);
     const int N = g.N, C = g.C;
-    const long long f0 = blockIdx.x;
+    const long long f0 = (long long)blockIdx.x * g.fpb;
+    const long long rem = g.n_frames - f0;
+    const int nfl = rem < g.fpb ? (int)rem : g.fpb;
     T* x = reinterpret_cast<T*>(smem);
-    T* X = x + (long long)N * C;
-    stage_in_pcm<T, LG, -1, false>(pcm, 0, g, f0, 1, N, aligned_in != 0);
+    T* X = x + (long long)N * C * g.fpb;
+    stage_in_pcm<T, LG, -1, false>(pcm, 0, g, f0, nfl, N, aligned_in != 0);
     __syncthreads();
-    const double inv_n = 1.0 / (double)N;
-    const unsigned fourN = 4u * (unsigned)N;
-    for (int q = threadIdx.x; q < N * C; q += blockDim.x) {
-        const int c = q / N, k = q - c * N;
-        const T* xc = x + (long long)c * N;
-        double acc = 0.0;
-        unsigned j = (unsigned)k % fourN;           // k * (2n + 1) mod 4N, advanced by 2k per sample
-        const unsigned step = (2u * (unsigned)k) % fourN;
-        for (int n = 0; n < N; ++n) {
-            acc = fma((double)xc[n], ct[j], acc);
-            j += step; if (j >= fourN) j -= fourN;
-        }
-        X[(long long)c * N + k] = (T)(acc * inv_n);
-    }
+    direct_product<T, true>(x, X, ct, N, nfl * C);
     __syncthreads();
-    pack_out_any<T, -1>((int)((long long)N * C * sizeof(T)), payload, absmax, g, f0, 1, N, aligned_out != 0);
+    pack_out_any<T, -1>((int)((long long)N * C * g.fpb * sizeof(T)), payload, absmax, g, f0, nfl, N, aligned_out != 0);
 }
 
 template <int UNUSED>
-__global__ void __launch_bounds__(256) k_p0_inv_direct(const unsigned char* __restrict__ payload, double* __restrict__ out,
-                                                       const double* __restrict__ ct, Geom g, int aligned_in) {
+__global__ void __launch_bounds__(1024) k_p0_inv_direct(const unsigned char* __restrict__ payload, double* __restrict__ out,
+                                                        const double* __restrict__ ct, Geom g, int aligned_in) {
     FRAD_DYN_SMEM(smem);
     const int N = g.N, C = g.C;
-    const long long f0 = blockIdx.x;
+    const long long f0 = (long long)blockIdx.x * g.fpb;
+    const long long rem = g.n_frames - f0;
+    const int nfl = rem < g.fpb ? (int)rem : g.fpb;
     double* X = reinterpret_cast<double*>(smem);
-    double* x = X + (long long)N * C;
-    unpack_in_any<-1>(payload, 0, g, f0, 1, N, aligned_in != 0);
+    double* x = X + (long long)N * C * g.fpb;
+    unpack_in_any<-1>(payload, 0, g, f0, nfl, N, aligned_in != 0);
     __syncthreads();
-    const unsigned fourN = 4u * (unsigned)N;
-    for (int q = threadIdx.x; q < N * C; q += blockDim.x) {
-        const int c = q / N, n = q - c * N;
-        const double* Xc = X + (long long)c * N;
-        double acc = 0.0;
-        const unsigned step = (2u * (unsigned)n + 1u) % fourN;
-        unsigned j = step;                          // k * (2n + 1) mod 4N for k = 1
-        for (int k = 1; k < N; ++k) {
-            acc = fma(Xc[k], ct[j], acc);
-            j += step; if (j >= fourN) j -= fourN;
-        }
-        x[(long long)c * N + n] = Xc[0] + 2.0 * acc;
-    }
+    direct_product<double, false>(X, x, ct, N, nfl * C);
     __syncthreads();
-    store_pcm_f64<-1, false>((int)((long long)N * C * sizeof(double)), out, g, f0, 1, N);
+    store_pcm_f64<-1, false>((int)((long long)N * C * g.fpb * sizeof(double)), out, g, f0, nfl, N);
 }
 
 }  // namespace frad

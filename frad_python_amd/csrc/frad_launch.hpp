@@ -50,4 +50,13 @@ int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const 
                        double* absmax, const Tables& tb, Geom g, int aligned_out);
 int launch_p0_inv_pers(const FastCfg& c, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb, Geom g);
 
+
+// Bluestein kernels for frame lengths that are not a power of two (frad_p0_blue.hip): 1 = launched,
+// 0 = not applicable (the caller falls back to the direct kernels), < 0 = FRAD_E_*
+int launch_p0_fwd_blue(int lg, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* absmax, Geom g, int aligned_out);
+int launch_p0_inv_blue(hipStream_t s, const unsigned char* pay, double* out, Geom g, int aligned_in);
+int blue_prepare(int N);
+void blue_clear();
+int blue_last_hip_error();
+
 }  // namespace frad

@@ -141,3 +141,38 @@ def test_cfg5_lossy_profile_sixty_seconds(gpu):
     lossy_psnr_build = 10 * np.log10(1.0 / np.mean((x[hop:] - got[hop:]) ** 2))
     lossy_psnr_ref = 10 * np.log10(1.0 / np.mean((x[hop:] - ref_out[hop:]) ** 2))
     assert abs(lossy_psnr_build - lossy_psnr_ref) < 0.01           # the codec's own loss (~19 dB at level 20) is unchanged
+
+
+def test_step_is_hip_graph_capturable(gpu):
+    """After frad_plan_prepare (and one eager call that settles the kernels' LDS attributes) the launches
+    make no allocation or synchronising call, so a whole encode -> overflow scan -> decode step can be
+    captured in a HIP graph and replayed (include/frad_hip.h: frad_plan_prepare)."""
+    torch, core, dev = gpu
+    N, C, F, bits = 2048, 2, 512, 32
+    core._lib.load().plan_prepare(N, False)
+    pcm = _signal(torch, dev, F * N, C, 7, "s16le")
+    pay = torch.empty((F, core._lib.load().payload_bytes(N, C, bits)), dtype=torch.uint8, device=dev)
+    am = torch.empty(F, dtype=torch.float64, device=dev)
+    out = torch.empty((F, N, C), dtype=torch.float64, device=dev)
+    flag = torch.zeros((), dtype=torch.int32, device=dev)
+
+    def step():
+        core.analogue_batch(0, pcm, "s16le", F, N, C, bits, check_overflow=False, out=pay, absmax=am)
+        core.overflow_scan(am, bits, flag)
+        core.digital_batch(0, pay, F, N, C, bits, out=out)
+    step()
+    torch.cuda.synchronize()
+    want_pay, want_out = pay.clone(), out.clone()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            step()
+    torch.cuda.synchronize()
+    for _ in range(2):
+        pay.zero_(); out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(pay, want_pay) and torch.equal(out, want_out)
+    assert int(flag.item()) == 0

@@ -144,11 +144,13 @@ def test_p0_little_endian_and_unaligned(be):
 
 
 @pytest.mark.parametrize("fmt", ["s16le", "f32le"])
-def test_p0_any_length_direct_kernel(be, fmt):
-    """Tail frames and odd sizes (SURVEY hard part 4): 896 = 48000 mod 2048, primes, tiny frames."""
+def test_p0_any_length(be, fmt):
+    """Tail frames and odd sizes (SURVEY hard part 4): 896 = 48000 mod 2048, primes, tiny frames.
+    float64 compute at N >= 96 runs the Bluestein kernels, everything else the direct cosine product."""
     rng = np.random.default_rng(15)
-    for (N, C, F) in _sizes(be, [(896, 2, 1), (7, 3, 2), (1, 1, 2), (2, 2, 1), (100, 1, 1)],
-                            [(896, 2, 3), (7, 3, 2), (1, 1, 2), (2, 2, 1), (100, 1, 2), (997, 2, 2), (1000, 2, 1), (64, 2, 2), (1920, 2, 1)]):
+    for (N, C, F) in _sizes(be, [(896, 2, 1), (7, 3, 2), (1, 1, 2), (2, 2, 1), (100, 1, 1), (131, 3, 2), (95, 2, 1)],
+                            [(896, 2, 3), (7, 3, 2), (1, 1, 2), (2, 2, 1), (100, 1, 2), (997, 2, 2), (1000, 2, 1), (64, 2, 2), (1920, 2, 1),
+                             (131, 3, 2), (3001, 1, 1), (1092, 8, 2), (4095, 2, 1), (2049, 4, 1)]):
         raw = synth.to_pcm(rng.uniform(-1, 1, (F * N, C)), fmt)
         for bits in (12, 32, 64):
             pay, am = be.analogue(0, raw, fmt, F, N, C, bits, False)
