@@ -42,6 +42,7 @@ class Decoder:
         self.asfh = ASFH()
         self.info = ASFH()
         self.buffer = b""
+        self._data, self._pos = b"", 0
         self.overlap_fragment = np.array([])          # tail of the last compact frame, [L, C]
         self.fix_error = fix_error
         self.broken_frame = False
@@ -119,27 +120,38 @@ class Decoder:
         return out
 
     # ------------------------------------------------------------------ stream parsing
+    # The parser walks `self._data` with a cursor (`self._pos`) instead of re-slicing the byte string after
+    # every header and payload: a 10-minute stream handed over in one process() call would otherwise copy
+    # its remaining tail ~4 times per frame.  `self.buffer` holds the unconsumed bytes between calls.
     def _lock_on_signature(self) -> bool:
         """Position the parser on the next FRM_SIGN (decoder.py:82-90): True once a header has begun."""
         sign = common.FRM_SIGN
         if self.asfh.buffer[:len(sign)] == sign:
             return True
-        at = self.buffer.find(sign)
+        at = self._data.find(sign, self._pos)
         if at < 0:
-            self.buffer = self.buffer[-(len(sign) - 1):]        # keep a possible split signature
+            self._pos = max(self._pos, len(self._data) - (len(sign) - 1))     # keep a possible split signature
             return False
         self.asfh.buffer = sign
-        self.buffer = self.buffer[at + len(sign):]
+        self._pos = at + len(sign)
         return True
+
+    def _read_header(self) -> str:
+        """Feed the header parser a window that always covers a whole header (<= 40 bytes)."""
+        window = self._data[self._pos:self._pos + 64]
+        state, rest = self.asfh.read(window)
+        self._pos += len(window) - len(rest)
+        return state
 
     def _take_frame(self, stream_was_empty: bool):
         """Cut the payload of the header just completed; None while it is still arriving."""
         need = self.asfh.frmbytes
         self.broken_frame = False
-        if len(self.buffer) < need:
+        if len(self._data) - self._pos < need:
             self.broken_frame = stream_was_empty                # process(b'') marks a truncated frame (decoder.py:58-60)
             return None
-        frad, self.buffer = self.buffer[:need], self.buffer[need:]
+        frad = self._data[self._pos:self._pos + need]
+        self._pos += need
         a = self.asfh
         if a.profile not in (0, 1, 4):
             raise NotImplementedError(f"profile {a.profile} is not built (upstream: in development)")
@@ -151,7 +163,13 @@ class Decoder:
 
     def process(self, stream: bytes) -> DecodeResult:
         """Parse as the reference does (decoder.py:51-108) but decode runs of like frames in one launch each."""
-        self.buffer += stream
+        self._data, self._pos = self.buffer + stream, 0
+        try:
+            return self._process(len(stream) == 0)
+        finally:
+            self.buffer, self._data, self._pos = self._data[self._pos:], b"", 0
+
+    def _process(self, stream_was_empty: bool) -> DecodeResult:
         pieces, frames = [], 0
         run_key, run = None, []
 
@@ -163,7 +181,7 @@ class Decoder:
 
         while True:
             if self.asfh.all_set:
-                got = self._take_frame(len(stream) == 0)
+                got = self._take_frame(stream_was_empty)
                 if got is None:
                     break
                 key, frad = got
@@ -175,7 +193,7 @@ class Decoder:
                 continue
             if not self._lock_on_signature():
                 break
-            state, self.buffer = self.asfh.read(self.buffer)
+            state = self._read_header()
             if state == "Incomplete":
                 break
             if state == "ForceFlush":

@@ -61,5 +61,24 @@ out.append(line("cfg5 p1 quantise (K7)", F * (N * C * 2 + N * C * 4 + 27 * C * 4
 out.append(line("cfg5 p1 dequantise+IDCT (K8)", F * (N * C * 4 + 27 * C * 4 + N * C * 8), timeit(lambda: core.p1_digital_batch(q, tq, N, C, 16, 48000)), F * hop * C))
 dec = core.p1_digital_batch(q, tq, N, C, 16, 48000)
 out.append(line("cfg5 overlap-add", F * (N * C * 8 + hop * C * 8), timeit(lambda: core.p1_overlap_add(dec, 16)), F * hop * C))
+# end to end through the streaming API (SURVEY 8d "separate line"): host bytes in -> FrAD stream bytes out and
+# back, i.e. H2D + kernels + D2H + the Python ASFH framer / CRC, one process() call per 60 s of audio
+import time  # noqa: E402
+from frad_python_amd import Decoder, Encoder  # noqa: E402
+secs = 60
+host = (np.random.default_rng(3).normal(0, 3000, (secs * 48000, 2)).clip(-32768, 32767)).astype("<i2").tobytes()
+for _ in range(2):
+    t0 = time.perf_counter()
+    enc_s = Encoder(0, 48000, 2, 32, 2048, "s16le")
+    r = enc_s.process(host); stream = r.buf + enc_s.flush().buf
+    t1 = time.perf_counter()
+    dec_s = Decoder()
+    d = dec_s.process(stream); tail = dec_s.flush()
+    t2 = time.perf_counter()
+S2 = secs * 48000 * 2
+out.append({"case": "e2e stream encode, host bytes -> FrAD bytes (60 s stereo s16, profile 0, 32 bit)", "ms": round((t1 - t0) * 1e3, 2),
+            "Gsamples/s": round(S2 / (t1 - t0) / 1e9, 3), "stream_bytes": len(stream)})
+out.append({"case": "e2e stream decode, FrAD bytes -> host float64", "ms": round((t2 - t1) * 1e3, 2),
+            "Gsamples/s": round(S2 / (t2 - t1) / 1e9, 3), "frames": int(d.frames)})
 for o_ in out:
     print(json.dumps(o_))
