@@ -484,14 +484,18 @@ template <int NW> __device__ __forceinline__ void unit_barrier(unsigned* ctr, un
     }
 }
 
-template <typename T, int BITS, int SH, int CC>
-__device__ __forceinline__ u64 pack_frame_pairs(const unsigned char* data, unsigned char* __restrict__ dst, bool le, int utid, int M) {
+template <typename T, int BITS, int SH, int CC, int M>
+__device__ __forceinline__ u64 pack_frame_pairs(const unsigned char* data, unsigned char* __restrict__ dst, bool le, int utid) {
     constexpr int U = unit_values(BITS), UB = unit_bytes(BITS);
     constexpr int V = U > 2 * CC ? U : 2 * CC, KB = V / CC;
-    const int tasks = (2 * M * CC) / V, uth = CC * 64;
+    constexpr int tasks = (2 * M * CC) / V, uth = CC * 64, ITER = tasks / uth;
+    static_assert(ITER * uth == tasks, "whole tasks per lane");
     double fm = 0.0;
     bool nan = false;
-    for (int u = utid; u < tasks; u += uth) {
+    // compile-time trip count: the LDS reads of several tasks are in flight before the first conversion
+#pragma unroll (ITER > 8 ? 8 : ITER)
+    for (int it = 0; it < ITER; ++it) {
+        const int u = utid + it * uth;
         u64 codes[V];
         const int s0 = (u * KB) >> 1;
 #pragma unroll
@@ -520,19 +524,19 @@ __device__ __forceinline__ u64 pack_frame_pairs(const unsigned char* data, unsig
     return nan ? 0x7ff8000000000000ULL : d2u(fm);             // np.max(np.abs(.)) propagates NaN
 }
 // out-of-line so that the six storage formats do not count against the transform's registers
-template <typename T, int SH, int CC>
+template <typename T, int SH, int CC, int M>
 __device__ FRAD_NOINLINE void pack_frame_pairs_any(int data_off, unsigned char* __restrict__ dst, int wmax_off, int bits,
-                                                   int le, int utid, int M) {
+                                                   int le, int utid) {
     FRAD_DYN_SMEM(smem);
     const unsigned char* data = smem + data_off;
     u64 mx;
     switch (bits) {
-        case 12: mx = pack_frame_pairs<T, 12, SH, CC>(data, dst, false, utid, M); break;
-        case 16: mx = pack_frame_pairs<T, 16, SH, CC>(data, dst, le != 0, utid, M); break;
-        case 24: mx = pack_frame_pairs<T, 24, SH, CC>(data, dst, le != 0, utid, M); break;
-        case 32: mx = pack_frame_pairs<T, 32, SH, CC>(data, dst, le != 0, utid, M); break;
-        case 48: mx = pack_frame_pairs<T, 48, SH, CC>(data, dst, le != 0, utid, M); break;
-        default: mx = pack_frame_pairs<T, 64, SH, CC>(data, dst, le != 0, utid, M); break;
+        case 12: mx = pack_frame_pairs<T, 12, SH, CC, M>(data, dst, false, utid); break;
+        case 16: mx = pack_frame_pairs<T, 16, SH, CC, M>(data, dst, le != 0, utid); break;
+        case 24: mx = pack_frame_pairs<T, 24, SH, CC, M>(data, dst, le != 0, utid); break;
+        case 32: mx = pack_frame_pairs<T, 32, SH, CC, M>(data, dst, le != 0, utid); break;
+        case 48: mx = pack_frame_pairs<T, 48, SH, CC, M>(data, dst, le != 0, utid); break;
+        default: mx = pack_frame_pairs<T, 64, SH, CC, M>(data, dst, le != 0, utid); break;
     }
     mx = wave_max_u64(mx);
     if ((threadIdx.x & 63) == 0) reinterpret_cast<u64*>(smem + wmax_off)[threadIdx.x >> 6] = mx;   // per-wave max, combined by the unit
@@ -658,7 +662,7 @@ k_p0_fwd_unit(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
 #pragma unroll
             for (int j = 0; j < 4; ++j) FRAD_OPAQUE(pf[i][j]);    // retire the prefetch before the store burst
         unit_barrier<CC>(ctr, epoch);
-        pack_frame_pairs_any<T, SH, CC>(data_off, payload + f * g.payload_stride, TB + 64, g.bits, g.le, utid, M);
+        pack_frame_pairs_any<T, SH, CC, M>(data_off, payload + f * g.payload_stride, TB + 64, g.bits, g.le, utid);
         unit_barrier<CC>(ctr, epoch);
         if (absmax != nullptr && utid0 == 0) {                // plain store: no atomics, no memset before the launch
             const u64* wm = reinterpret_cast<const u64*>(smem + TB + 64) + unit * CC;
@@ -674,23 +678,28 @@ k_p0_fwd_unit(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
 // store instruction of a wave writes 64 x 16 contiguous bytes.  Row n of channel c is component
 // (n&3 in {1,2}) of slot z[n>>2] (n even) or z[M-1-(n>>2)] (n odd) -- Makhoul's permutation undone on the
 // read side with conflict-free 8-byte LDS reads.
-template <int SH, int CC>
-__device__ FRAD_NOINLINE void store_frame_rows(int data_off, double* __restrict__ dstf, int utid, int M) {
+template <int SH, int CC, int M>
+__device__ FRAD_NOINLINE void store_frame_rows(int data_off, double* __restrict__ dstf, int utid) {
     FRAD_DYN_SMEM(smem);
     const double* data = reinterpret_cast<const double*>(smem + data_off);
-    const int N = 2 * M, uth = CC * 64;
+    constexpr int N = 2 * M, uth = CC * 64;
     auto sample = [&](int c, int n) -> double {
         const int q = n >> 2, r = n & 3;
         const int slot = (r & 1) ? (M - 1 - q) : q;
         return data[((long long)c * M + phys<double, SH>(slot)) * 2 + ((r == 1) | (r == 2))];
     };
+    // compile-time trip counts: several rows' LDS reads are in flight before the first store
     if constexpr (CC == 2) {
-        for (int n = utid; n < N; n += uth) {
+#pragma unroll 8
+        for (int i = 0; i < N / uth; ++i) {
+            const int n = utid + i * uth;
             v2d v = {sample(0, n), sample(1, n)};
             FRAD_GPTR(v2d, dstf)[n] = v;
         }
     } else {
-        for (int p = utid; p < N / 2; p += uth) {
+#pragma unroll 8
+        for (int i = 0; i < N / 2 / uth; ++i) {
+            const int p = utid + i * uth;
             v2d v = {sample(0, 2 * p), sample(0, 2 * p + 1)};
             FRAD_GPTR(v2d, dstf)[p] = v;
         }
@@ -782,7 +791,7 @@ k_p0_inv_unit(const unsigned char* __restrict__ payload, double* __restrict__ ou
 #pragma unroll
                 for (int j = 0; j < UB / 4; ++j) FRAD_OPAQUE(pf[i][w][j]);
         unit_barrier<CC>(ctr, epoch);
-        store_frame_rows<SH, CC>(data_off, out + f * (long long)N * CC, utid, M);
+        store_frame_rows<SH, CC, M>(data_off, out + f * (long long)N * CC, utid);
         unit_barrier<CC>(ctr, epoch);
         f = next;
     }
