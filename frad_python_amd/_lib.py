@@ -35,6 +35,7 @@ SYMBOLS = {
     "frad_p1_analogue": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_int32, c_int64, c_int32, c_int32, c_int32,
                                  c_double, c_uint32, c_void_p, c_void_p, c_void_p]),
     "frad_p1_digital": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "frad_crc32_frames": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "frad_p1_overlap_add": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
@@ -77,6 +78,9 @@ class FradLib:
     def p0_analogue(self, pcm, dtype, n_frames, N, C, frame_stride, bits, flags, payload, payload_stride, absmax, stream=0):
         self._check(self.dll.frad_p0_analogue(pcm, dtype, n_frames, N, C, frame_stride, bits, flags, payload,
                                                payload_stride, absmax, stream))
+
+    def crc32_frames(self, data, stride, n_frames, nbytes, out, stream=0):
+        self._check(self.dll.frad_crc32_frames(data, stride, n_frames, nbytes, out, stream))
 
     def p0_overflow_scan(self, absmax, n_frames, bits, flag, stream=0):
         self._check(self.dll.frad_p0_overflow_scan(absmax, n_frames, bits, flag, stream))

@@ -38,6 +38,30 @@ class HipBridge:
                 out.append((host[i].tobytes(), enc.bits))
         return out
 
+    def lossless_encode_stream(self, profile, pcm: bytes, fmt, n_frames, N, C, bits, little_endian, head_fn,
+                               raw_be_ints=True):
+        """Whole batch -> finished stream bytes, assembled on the device: the payload kernel writes every
+        frame behind a 32-byte hole, ``frad_crc32_frames`` fills in the checksums, the constant part of the
+        header (``head_fn(payload_bytes)`` -> 28 bytes, tools/asfh.py) is broadcast, and one D2H copy returns
+        the result.  None when a frame needs a deeper format or a 64-bit length: the caller then goes frame
+        by frame through ``lossless_encode``."""
+        t, core = self.torch, self.core
+        if bits not in core.DEPTHS:
+            bits = 16
+        nb = core._lib.load().payload_bytes(N, C, bits)
+        if n_frames == 0 or nb >= 0xFFFFFFFF:
+            return None
+        stream = t.empty((n_frames, 32 + nb), dtype=t.uint8, device=self.device)
+        pay = stream[:, 32:]
+        enc = core.analogue_batch(profile, self._up(pcm), fmt, n_frames, N, C, bits, little_endian,
+                                  raw_be_ints=raw_be_ints, out=pay)
+        if enc.escalated:
+            return None
+        crc = core.crc32_frames(pay, nb)
+        stream[:, :28] = t.frombuffer(bytearray(head_fn(nb)), dtype=t.uint8).to(self.device)
+        stream[:, 28:32] = crc.view(t.uint8).view(n_frames, 4).flip(1)       # big-endian, as int.to_bytes(4, "big")
+        return stream.cpu().numpy().tobytes()
+
     def lossless_decode(self, profile, payloads: list, N, C, bits, little_endian) -> np.ndarray:
         n = len(payloads)
         nb = len(payloads[0])

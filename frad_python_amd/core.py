@@ -30,6 +30,12 @@ def _require_cuda(t: torch.Tensor, what: str):
         raise ValueError(f"{what} must be contiguous")
 
 
+def _require_cuda_any(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what} must live in MI355X device memory (got a {t.device} tensor); "
+                           "the transform core has no CPU path")
+
+
 def _stream_ptr() -> int:
     return int(torch.cuda.current_stream().cuda_stream)
 
@@ -120,6 +126,18 @@ def overflow_scan(absmax: torch.Tensor, bits: int, flag: torch.Tensor) -> None:
         raise TypeError("absmax must be float64 and flag int32")
     with torch.cuda.device(absmax.device):
         _lib.load().p0_overflow_scan(absmax.data_ptr(), absmax.numel(), bits, flag.data_ptr(), _stream_ptr())
+
+
+def crc32_frames(payload: torch.Tensor, nbytes: int) -> torch.Tensor:
+    """zlib.crc32 of ``payload[i, :nbytes]`` for every row, as int32 bit patterns on the device
+    (the checksum ASFH.write stores in a lossless frame header, tools/asfh.py:51-73)."""
+    _require_cuda_any(payload, "payload")
+    if payload.dtype != torch.uint8 or payload.dim() != 2 or payload.stride(1) != 1 or payload.shape[1] < nbytes:
+        raise ValueError("payload must be a uint8 [n_frames, >= nbytes] tensor with unit column stride")
+    out = torch.empty(payload.shape[0], dtype=torch.int32, device=payload.device)
+    with torch.cuda.device(payload.device):
+        _lib.load().crc32_frames(payload.data_ptr(), payload.stride(0), payload.shape[0], nbytes, out.data_ptr(), _stream_ptr())
+    return out
 
 
 def digital_batch(profile: int, payload: torch.Tensor, n_frames: int, N: int, C: int, bits: int,

@@ -58,5 +58,8 @@ int launch_p0_inv_blue(hipStream_t s, const unsigned char* pay, double* out, Geo
 int blue_prepare(int N);
 void blue_clear();
 int blue_last_hip_error();
+// CRC-32 tables (frad_crc.hip)
+void crc_clear();
+int crc_last_hip_error();
 
 }  // namespace frad

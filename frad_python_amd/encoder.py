@@ -78,6 +78,14 @@ class Encoder:
                 out.append(self._emit(self._p1_pack(q[i].reshape(-1), tq[i].reshape(-1)), _P1_DEPTHS.index(bits), n_valid))
         else:
             bits = self.bit_depth if self.bit_depth in _LOSSLESS_DEPTHS else 16
+            whole = getattr(self.bridge, "lossless_encode_stream", None)
+            if whole is not None and not self.asfh.ecc and n_frames > 1:
+                # headers and checksums on the device, one copy back (bridge.py); falls through when a frame escalates
+                a = self.asfh
+                a.bit_depth_index, a.channels, a.fsize, a.srate = _LOSSLESS_DEPTHS.index(bits), C, n_eff, self.srate
+                got = whole(prof, pcm, self.pcm_format_name, n_frames, n_eff, C, bits, a.endian, a.lossless_head)
+                if got is not None:
+                    return got
             for frad, used in self.bridge.lossless_encode(prof, pcm, self.pcm_format_name, n_frames, n_eff, C, bits, self.asfh.endian):
                 out.append(self._emit(frad, _LOSSLESS_DEPTHS.index(used), n_eff))
         return b"".join(out)

@@ -64,6 +64,10 @@ class ASFH:
     def _prefix(self, length: int) -> bytes:
         return FRM_SIGN + length.to_bytes(4, "big") + encode_pfb(self.profile, self.ecc, self.endian, self.bit_depth_index)
 
+    def lossless_head(self, length: int) -> bytes:
+        """The 28 header bytes of a lossless frame that do not depend on its payload (the CRC-32 follows)."""
+        return self._prefix(length) + _LOSSLESS_TAIL.pack(self.channels - 1, self.ecc_dsize, self.ecc_codesize, self.srate, self.fsize)
+
     def write(self, frad: bytes) -> bytes:
         parts = [self._prefix(len(frad))]
         if self.profile in COMPACT:

@@ -128,6 +128,12 @@ int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32
 int frad_p1_overlap_add(const double* frames, int64_t n_frames, int32_t N, int32_t C, int32_t overlap_ratio,
                         const double* prev_tail, double* ola_out, double* next_tail, void* stream);
 
+/* ---- frame header checksum (row 8f #1) --------------------------------------------------------
+ * crc_out[i] = zlib.crc32 of the `nbytes` payload bytes of frame i (at data + i*stride), the value
+ * ASFH.write puts into a lossless frame's header (src/libfrad/tools/asfh.py:51-73), so a batch's
+ * stream can be assembled without a host pass over the payload.                                   */
+int frad_crc32_frames(const void* data, int64_t stride, int64_t n_frames, int64_t nbytes, uint32_t* crc_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,14 @@ class EmuBackend:
         fn(buf.ctypes.data + offset, stride, F, N, C, bits, int(le), out.ctypes.data)
         return out[:F]
 
+    def crc32_frames(self, rows: np.ndarray, nbytes, offset=0):
+        F, stride = rows.shape
+        buf = np.zeros(F * stride + offset + 64, np.uint8)
+        buf[offset:offset + F * stride] = rows.reshape(-1)
+        out = np.zeros(max(F, 1), np.uint32)
+        self.lib.crc32_frames(buf.ctypes.data + offset, stride, F, nbytes, out.ctypes.data)
+        return out[:F]
+
     def overflow_scan(self, absmax, bits, flag0=0):
         am = np.ascontiguousarray(absmax, np.float64)
         flag = np.array([flag0], np.int32)
@@ -131,6 +139,17 @@ class GpuBackend:
         out = core.digital_batch(profile, view, F, N, C, bits, le, payload_stride=stride)
         t.cuda.synchronize()
         return out.cpu().numpy()
+
+    def crc32_frames(self, rows: np.ndarray, nbytes, offset=0):
+        from frad_python_amd import core
+        t = self.torch
+        F, stride = rows.shape
+        flat = t.zeros(F * stride + offset + 64, dtype=t.uint8, device=self.dev)
+        flat[offset:offset + F * stride] = t.from_numpy(np.ascontiguousarray(rows).reshape(-1)).to(self.dev)
+        view = flat[offset:offset + F * stride].view(F, stride)
+        out = core.crc32_frames(view, nbytes)
+        t.cuda.synchronize()
+        return out.cpu().numpy().view(np.uint32)
 
     def overflow_scan(self, absmax, bits, flag0=0):
         from frad_python_amd import core

@@ -211,6 +211,22 @@ def test_overflow_scan_matches_escalation_rule(be):
     assert be.overflow_scan(np.zeros(0), 32) == 0
 
 
+def test_crc32_of_frame_payloads(be):
+    """frad_crc32_frames == zlib.crc32 of each payload, the checksum of a lossless frame header (tools/asfh.py:69-76)"""
+    import zlib
+    rng = np.random.default_rng(6)
+    sizes = [0, 1, 3, 255, 256, 257, 4099, 16384] if be.name == "emu" else [0, 1, 3, 255, 256, 257, 4099, 16384, 16385, 40000, 131072, 196611]
+    for nbytes in sizes:
+        for (F, pad, offset) in ((5, 0, 0), (2, 7, 3)):
+            if nbytes == 0 and pad == 0:
+                pad = 16
+            rows = rng.integers(0, 256, (F, nbytes + pad), dtype=np.uint8)
+            rows[1, :nbytes] = 0                                   # all-zero payload: only the initial value matters
+            got = be.crc32_frames(rows, nbytes, offset=offset)
+            want = np.array([zlib.crc32(rows[i, :nbytes].tobytes()) for i in range(F)], np.uint32)
+            assert np.array_equal(got, want), (nbytes, F, pad, offset)
+
+
 def test_empty_batch(be):
     pay, am = be.analogue(0, np.zeros(0, np.int16), "s16le", 0, 2048, 2, 32, False)
     assert pay.shape[0] == 0
