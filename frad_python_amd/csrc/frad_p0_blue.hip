@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(1024) k_p0_fwd_blue(const unsigned char* __res
     double* X = reinterpret_cast<double*>(smem + xoff);
     const unsigned char* src = pcm + ((f * g.frame_stride * C) << LG);
     const double inv_n = 1.0 / (double)N;
+    const bool whole = g.in_mode != 0;                       // X area holds all C channels: one whole-frame pack at the end
     for (int c0 = 0; c0 < C; c0 += cg) {
         const int cgn = C - c0 < cg ? C - c0 : cg;
         for (int q = threadIdx.x; q < N * cgn; q += blockDim.x) {           // a[slot] = v[slot] conj(w_slot)
@@ -73,12 +74,16 @@ __global__ void __launch_bounds__(1024) k_p0_fwd_blue(const unsigned char* __res
         if (cf < cgn) {
             for (int k = t; k < N; k += TEAM) {
                 const cx<double> z = buf[phys<double, SH>(k)], p = pw[k];
-                X[(long long)(c0 + cf) * N + k] = (z.x * p.x - z.y * p.y) * inv_n;
+                X[(long long)((whole ? c0 : 0) + cf) * N + k] = (z.x * p.x - z.y * p.y) * inv_n;
             }
         }
         __syncthreads();
+        if (!whole) {                                        // big frames: pack this channel group now, per value
+            pack_out_group<double, -1>(xoff, payload, absmax, g, f, N, c0, cgn);
+            __syncthreads();
+        }
     }
-    pack_out_any<double, -1>(xoff, payload, absmax, g, f, 1, N, aligned_out != 0);
+    if (whole) pack_out_any<double, -1>(xoff, payload, absmax, g, f, 1, N, aligned_out != 0);
 }
 
 template <int LOG2L>
@@ -95,14 +100,19 @@ __global__ void __launch_bounds__(1024) k_p0_inv_blue(const unsigned char* __res
     cx<double>* buf = bufs + (long long)cf * L;
     const int xoff = cg * L * 16;
     double* X = reinterpret_cast<double*>(smem + xoff);
-    unpack_in_any<-1>(payload, xoff, g, f, 1, N, aligned_in != 0);
+    const bool whole = g.in_mode != 0;
+    if (whole) unpack_in_any<-1>(payload, xoff, g, f, 1, N, aligned_in != 0);
     __syncthreads();
     const int half = (N + 1) / 2;                            // slots [0, half) hold the even time samples
     for (int c0 = 0; c0 < C; c0 += cg) {
         const int cgn = C - c0 < cg ? C - c0 : cg;
+        if (!whole) {
+            unpack_in_group<-1>(payload, xoff, g, f, N, c0, cgn);
+            __syncthreads();
+        }
         for (int q = threadIdx.x; q < N * cgn; q += blockDim.x) {           // conj(A[k]) conj(w_k)
             const int k = q / cgn, j = q - k * cgn;
-            const double* Xc = X + (long long)(c0 + j) * N;
+            const double* Xc = X + (long long)((whole ? c0 : 0) + j) * N;
             const cx<double> a = {Xc[k], k > 0 ? Xc[N - k] : 0.0};
             bufs[(long long)j * L + phys<double, SH>(k)] = cmul(a, pw[k]);
         }
@@ -113,16 +123,20 @@ __global__ void __launch_bounds__(1024) k_p0_inv_blue(const unsigned char* __res
         __syncthreads();
         blue_convolve<LOG2L>(buf, t, tw, bhat);
         if (cf < cgn) {
-            double* xc = X + (long long)(c0 + cf) * N;                       // this channel's X has been consumed above
+            double* xc = X + (long long)((whole ? c0 : 0) + cf) * N;         // this channel's X has been consumed above
             for (int n = t; n < N; n += TEAM) {
                 const cx<double> z = buf[phys<double, SH>(n)], w = wconj[n];
                 const int time = n < half ? 2 * n : 2 * (N - 1 - n) + 1;
-                xc[time] = z.x * w.x - z.y * w.y;
+                xc[whole ? time : n] = z.x * w.x - z.y * w.y;                // group mode: store_pcm_group undoes the permutation
             }
         }
         __syncthreads();
+        if (!whole) {
+            store_pcm_group<-1>(xoff, out, g, f, N, c0, cgn);
+            __syncthreads();
+        }
     }
-    store_pcm_f64<-1, false>(xoff, out, g, f, 1, N);
+    if (whole) store_pcm_f64<-1, false>(xoff, out, g, f, 1, N);
 }
 
 namespace {
@@ -212,8 +226,8 @@ int get_blue(int N, int log2l, BlueTable& out) {
     return FRAD_OK;
 }
 
-struct BlueCfg { bool ok = false; int log2l = 0, cg = 0, threads = 0; size_t lds = 0; };
-BlueCfg blue_cfg(int N, int C) {
+struct BlueCfg { bool ok = false; int log2l = 0, cg = 0, threads = 0, whole = 0; size_t lds = 0; };
+BlueCfg blue_cfg(int N, int C, int bits, bool fwd) {
     BlueCfg c;
     if (N < 96 || N > 4096) return c;                        // tiny frames: the direct product is cheaper
     if (const char* e = getenv("FRAD_TUNE_NO_BLUE")) { if (atoi(e) != 0) return c; }   // A/B knob, not part of the ABI
@@ -221,13 +235,21 @@ BlueCfg blue_cfg(int N, int C) {
     while ((1 << l2) < 2 * N - 1) ++l2;
     if (l2 > 13) return c;
     const int team = team_for(l2);
-    const size_t xb = (size_t)C * N * 8, per = (size_t)(1 << l2) * 16;
-    if (xb + per > kLds) return c;
-    long long cg = (long long)((kLds - xb) / per);
+    const size_t per = (size_t)(1 << l2) * 16, xall = (size_t)C * N * 8;
+    long long cg = 0;
+    if (xall + per <= kLds) {                                // whole frame: X of all channels next to cg transform buffers
+        cg = (long long)((kLds - xall) / per);
+        c.whole = 1;
+    } else {                                                 // big frame: X of one channel group at a time, per-value I/O
+        cg = (long long)(kLds / (per + (size_t)N * 8));
+        if (fwd && bits == 12 && (C & 1)) return c;          // packing: 12-bit pairs must not straddle groups (reads may)
+    }
     if (cg > C) cg = C;
     if (cg * team > 1024) cg = 1024 / team;
+    if (!c.whole && fwd && bits == 12) cg &= ~1LL;
     if (cg < 1) return c;
-    c.ok = true; c.log2l = l2; c.cg = (int)cg; c.threads = (int)cg * team; c.lds = xb + (size_t)cg * per;
+    c.ok = true; c.log2l = l2; c.cg = (int)cg; c.threads = (int)cg * team;
+    c.lds = (size_t)cg * per + (c.whole ? xall : (size_t)cg * N * 8);
     return c;
 }
 
@@ -246,8 +268,8 @@ void go_inv(const BlueCfg& c, dim3 grid, hipStream_t s, const unsigned char* pay
     hipLaunchKernelGGL((k_p0_inv_blue<LOG2L>), grid, dim3(c.threads), c.lds, s, pay, out, tw, t.wconj, t.bhat, t.pw, g, ai);
 }
 
-int tables_for(int N, int C, BlueCfg& c, BlueTable& t, const cx<double>** tw) {
-    c = blue_cfg(N, C);
+int tables_for(int N, int C, int bits, bool fwd, BlueCfg& c, BlueTable& t, const cx<double>** tw) {
+    c = blue_cfg(N, C, bits, fwd);
     if (!c.ok) return 0;
     Tables ft; int rc = get_tables(c.log2l, false, ft);
     if (rc != FRAD_OK) return rc;
@@ -263,7 +285,7 @@ int blue_last_hip_error() { return g_last; }
 
 int blue_prepare(int N) {
     BlueCfg c; BlueTable t; const cx<double>* tw = nullptr;
-    const int r = tables_for(N, 1, c, t, &tw);
+    const int r = tables_for(N, 1, 32, true, c, t, &tw);
     return r < 0 ? r : FRAD_OK;
 }
 
@@ -277,10 +299,10 @@ void blue_clear() {
 int launch_p0_fwd_blue(int lg, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* absmax, Geom g, int aligned_out) {
     if (g.n_frames > 0x7fffffffLL) return 0;
     BlueCfg c; BlueTable t; const cx<double>* tw = nullptr;
-    const int r = tables_for(g.N, g.C, c, t, &tw);
+    const int r = tables_for(g.N, g.C, g.bits, true, c, t, &tw);
     if (r <= 0) return r;
     if (absmax) BCHK(hipMemsetAsync(absmax, 0, sizeof(double) * (size_t)g.n_frames, s));       // atomicMax target
-    g.cg = c.cg; g.fpb = 1;
+    g.cg = c.cg; g.fpb = 1; g.in_mode = c.whole;
     dim3 grid((unsigned)g.n_frames);
     switch (c.log2l) {
         case 8: go_fwd<8>(lg, c, grid, s, pcm, pay, absmax, tw, t, g, aligned_out); break;
@@ -296,9 +318,9 @@ int launch_p0_fwd_blue(int lg, hipStream_t s, const unsigned char* pcm, unsigned
 int launch_p0_inv_blue(hipStream_t s, const unsigned char* pay, double* out, Geom g, int aligned_in) {
     if (g.n_frames > 0x7fffffffLL) return 0;
     BlueCfg c; BlueTable t; const cx<double>* tw = nullptr;
-    const int r = tables_for(g.N, g.C, c, t, &tw);
+    const int r = tables_for(g.N, g.C, g.bits, false, c, t, &tw);
     if (r <= 0) return r;
-    g.cg = c.cg; g.fpb = 1;
+    g.cg = c.cg; g.fpb = 1; g.in_mode = c.whole;
     dim3 grid((unsigned)g.n_frames);
     switch (c.log2l) {
         case 8: go_inv<8>(c, grid, s, pay, out, tw, t, g, aligned_in); break;

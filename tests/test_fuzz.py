@@ -1,0 +1,77 @@
+"""Randomised differential test on the MI355X: profile 0 / 4 over random geometry (frame length incl. odd
+sizes, channels, PCM format, storage depth, endianness, buffer offsets) against the oracle, under the same
+tolerance contract as tests/test_parity.py.  Fixed seed; geometries beyond the documented LDS limits must
+be refused with FRAD_E_UNSUPPORTED (-2), never mis-computed."""
+import numpy as np
+import pytest
+
+from frad_python_amd import synth
+from oracle import frad_oracle as fo
+from helpers import GpuBackend, oracle_frames, payload_values
+from test_parity import EPS32, EPS64
+
+pytestmark = pytest.mark.gpu
+FORMATS = ["s16le", "s16be", "u8", "s8", "s32le", "u16le", "f32le", "f32be", "f64le", "f64be", "f16le", "s64le", "u32be"]
+
+
+def _check(be, rng, profile, N, C, F, fmt, bits, le, offset):
+    from frad_python_amd._lib import FradError
+    raw = synth.to_pcm(rng.uniform(-1, 1, (F * N, C)), fmt)
+    try:
+        pay, am = be.analogue(profile, raw, fmt, F, N, C, bits, le, offset=offset)
+    except FradError as e:
+        assert e.status == -2, (profile, N, C, F, fmt, bits, le, offset, str(e))
+        return "refused"
+    ref = oracle_frames(fo, profile, raw, fmt, F, N, C, bits, le)
+    f32 = fmt.startswith(("f32", "f16"))
+    lg = max(np.log2(N), 1.0)
+    # 12-bit payloads are always big-endian (profile0.py:29-30); the helper mirrors that
+    for f in range(F):
+        if profile == 4:
+            assert np.array_equal(pay[f], ref[f][0]), ("p4 payload", N, C, F, fmt, bits, le, offset, f)
+            continue
+        gv, wv = payload_values(fo, pay[f], bits, le), payload_values(fo, ref[f][0], bits, le)
+        store = {12: 2.0 ** -7, 16: 2.0 ** -10, 24: 2.0 ** -15, 32: 2.0 ** -23, 48: 2.0 ** -36, 64: 0.0}[bits]
+        # unscaled big-endian ints (the reference's quirk) overflow the small storage floats: +-inf must match exactly
+        fin = np.isfinite(wv)
+        assert np.array_equal(gv[~fin], wv[~fin]), ("p0 non-finite", N, C, F, fmt, bits, le, offset, f)
+        if not fin.any():
+            continue
+        tol = (store + (8 * EPS32 if f32 else 8 * EPS64) * lg) * max(np.max(np.abs(wv[fin])), 1e-300)
+        assert np.max(np.abs(gv[fin] - wv[fin])) <= 2 * tol, ("p0 payload", N, C, F, fmt, bits, le, offset, f)
+    try:
+        dec = be.digital(profile, np.stack([r[0] for r in ref]), F, N, C, bits, le, offset=offset)
+    except FradError as e:
+        # what encodes must decode, except beyond the documented limit (non-power-of-two N > 4096 with N*C*16 > 160 KiB)
+        assert e.status == -2 and N > 4096 and (N & (N - 1)), ("decode refused", profile, N, C, F, fmt, bits, le, offset)
+        return "refused"
+    for f in range(F):
+        if profile == 4:
+            assert np.array_equal(dec[f], ref[f][1]), ("p4 decode", N, C, F, fmt, bits, le, offset, f)
+        else:
+            scale = max(1.0, float(np.max(np.abs(ref[f][1]))))
+            assert np.all(np.isfinite(dec[f])) and np.max(np.abs(dec[f] - ref[f][1])) <= 16 * EPS64 * lg * scale, ("p0 decode", N, C, F, fmt, bits, le, offset, f)
+    return "ok"
+
+
+def test_random_geometries_against_oracle():
+    be = GpuBackend()
+    rng = np.random.default_rng(20261004)
+    done = {"ok": 0, "refused": 0}
+    pow2 = [128, 256, 512, 1024, 2048, 4096, 8192]
+    for i in range(220):
+        profile = int(rng.choice([0, 0, 4]))
+        kind = rng.integers(0, 3)
+        N = int(rng.choice(pow2)) if kind == 0 else int(rng.integers(1, 3000)) if kind == 1 else int(rng.choice([896, 1920, 441, 1000, 1536, 2047, 2049, 96, 95, 97]))
+        C = int(rng.choice([1, 1, 2, 2, 2, 3, 5, 6, 8]))
+        F = int(rng.choice([1, 2, 3, 7, 33]))
+        while N * C * F > 600000:
+            F = max(1, F // 2)
+            if F == 1 and N * C > 600000:
+                C = 1
+        fmt = str(rng.choice(FORMATS))
+        bits = int(rng.choice(fo.DEPTHS))
+        le = bool(rng.integers(0, 2))
+        offset = int(rng.choice([0, 0, 0, 2, 6]))
+        done[_check(be, rng, profile, N, C, F, fmt, bits, le, offset)] += 1
+    assert done["ok"] >= 150, done

@@ -50,6 +50,22 @@ enc = core.analogue_batch(0, pcm4, "f32le", F, N, C, 32, check_overflow=False)
 o = torch.empty((F, N, C), dtype=torch.float64, device=dev)
 out.append(line("cfg4 p0 encode f32 8ch N=4096 (f32 compute)", S * 8, timeit(lambda: core.analogue_batch(0, pcm4, "f32le", F, N, C, 32, check_overflow=False, out=enc.payload, absmax=enc.absmax)), S))
 out.append(line("cfg4 p0 decode (f64, channel-group kernel)", S * 12, timeit(lambda: core.digital_batch(0, enc.payload, F, N, C, 32, out=o)), S))
+# cfg 3: one GPU's share (512) of 4096 x 1 s stereo clips: 23 full frames + an 896-sample tail frame per clip
+clips, n3 = 512, 48000
+full3, tail3 = n3 // 2048, n3 % 2048
+pcm3 = (torch.randn((clips, n3, 2), generator=g, device=dev) * 8000).clamp(-32768, 32767).to(torch.int16)
+body3, tails3 = pcm3[:, :full3 * 2048].contiguous(), pcm3[:, full3 * 2048:].contiguous()
+F3 = clips * full3
+enc3 = core.analogue_batch(0, body3, "s16le", F3, 2048, 2, 32, check_overflow=False)
+o3 = torch.empty((F3, 2048, 2), dtype=torch.float64, device=dev)
+S3 = F3 * 2048 * 2
+out.append(line("cfg3 full frames encode (11776 x N=2048)", S3 * 6, timeit(lambda: core.analogue_batch(0, body3, "s16le", F3, 2048, 2, 32, check_overflow=False, out=enc3.payload, absmax=enc3.absmax)), S3))
+out.append(line("cfg3 full frames decode", S3 * 12, timeit(lambda: core.digital_batch(0, enc3.payload, F3, 2048, 2, 32, out=o3)), S3))
+et3 = core.analogue_batch(0, tails3, "s16le", clips, tail3, 2, 32, check_overflow=False)
+ot3 = torch.empty((clips, tail3, 2), dtype=torch.float64, device=dev)
+St = clips * tail3 * 2
+out.append(line("cfg3 tail frames encode (512 x N=896, Bluestein)", St * 6, timeit(lambda: core.analogue_batch(0, tails3, "s16le", clips, tail3, 2, 32, check_overflow=False, out=et3.payload, absmax=et3.absmax)), St))
+out.append(line("cfg3 tail frames decode (512 x N=896, Bluestein)", St * 12, timeit(lambda: core.digital_batch(0, et3.payload, clips, tail3, 2, 32, out=ot3)), St))
 # cfg 5: 60 s stereo s16, profile 1, N = 2048, hop 1920, loss level 20
 N, C, hop = 2048, 2, 1920
 n = 60 * 48000
