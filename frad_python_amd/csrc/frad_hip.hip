@@ -417,7 +417,9 @@ int frad_p0_digital(const void* payload, int64_t payload_stride, int64_t n_frame
         if (c.cg == C && ai && C <= 2 && ((long long)N * C) % 32 == 0) g.cc_fast = C;
         if (c.cg == C && C <= 2 && aligned16(pcm_out)) g.in_mode = C;      // decode: quad store for C = 1 / 2
         dim3 grid((unsigned)((n_frames + c.fpb - 1) / c.fpb));
-        if (!launch_p0_inv_pers(c, s, in, pcm_out, tb, g)) {
+        if (c.cg < C && launch_p0_inv_grp2(c, s, in, pcm_out, tb, g)) {
+            // whole-row two-pass kernel took it
+        } else if (!launch_p0_inv_pers(c, s, in, pcm_out, tb, g)) {
             rc = launch_p0_inv(c, grid, s, in, pcm_out, tb, g, ai);
             if (rc != FRAD_OK) return rc;
         }

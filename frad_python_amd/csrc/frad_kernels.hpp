@@ -631,7 +631,24 @@ __device__ FRAD_NOINLINE void stage_in_pcm_group(const unsigned char* __restrict
     unsigned char* smem = smem_base_ + smem_off;
     const int N = g.N, C = g.C;
     const unsigned char* src = pcm + ((f * g.frame_stride * C) << LG);
-    for (int q = threadIdx.x; q < N * cgn; q += blockDim.x) {
+    const int total = N * cgn, TH = blockDim.x;
+    int q0 = threadIdx.x;
+    if (g.n_valid == N) {                                    // batches of 8 element loads in flight per lane
+        for (; q0 + 7 * TH < total; q0 += 8 * TH) {
+            u64 raw[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int q = q0 + i * TH, n = q / cgn, j = q - n * cgn;
+                raw[i] = load_raw(src + (((long long)n * C + c0 + j) << LG), LG);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int q = q0 + i * TH, n = q / cgn, j = q - n * cgn;
+                xslot<T, SH>(smem, j, slots, makhoul(n, N)) = cvt_pcm<T>(raw[i], g.dtype, g.raw_be);
+            }
+        }
+    }
+    for (int q = q0; q < total; q += TH) {
         const int n = q / cgn, j = q - n * cgn;
         const long long e = (long long)n * C + c0 + j;
         const T v = n < g.n_valid ? cvt_pcm<T>(load_raw(src + (e << LG), LG), g.dtype, g.raw_be) : (T)0;
@@ -690,7 +707,67 @@ __device__ FRAD_NOINLINE void unpack_in_group(const unsigned char* __restrict__ 
     const bool le = g.le && (g.bits % 8 == 0);
     const unsigned char* src = payload + f * g.payload_stride;
     const bool sized = (g.bits == 16 || g.bits == 32 || g.bits == 64) && (reinterpret_cast<uintptr_t>(src) % (g.bits / 8) == 0);
-    for (int q = threadIdx.x; q < N * cgn; q += blockDim.x) {
+    const int total = N * cgn, T = blockDim.x;
+    int q0 = threadIdx.x;
+    {
+        // The group's share of a payload row (cgn values) is contiguous: when it is whole, aligned 16-byte pieces, a
+        // lane loads a piece at a time, 8 pieces in flight -- one block per CU runs here, so only bytes in flight
+        // per lane hide the memory latency (element loads reach ~0.6 TB/s).
+        const int nbv = g.bits >> 3;                          // bytes per value (16/32/64 bit)
+        const long long rowb = (long long)C * nbv, pieceb = (long long)cgn * nbv;
+        if (sized && pieceb % 16 == 0 && rowb % 16 == 0 && ((long long)c0 * nbv) % 16 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            const int ppr = (int)(pieceb / 16), vpp = 16 / nbv;          // pieces per row, values per piece
+            const int pieces = N * ppr;
+            int p0 = threadIdx.x;
+            auto emit = [&](int p, const uint32_t (&w)[4]) {
+                const int k = p / ppr, pi = p - k * ppr;
+                for (int v = 0; v < vpp; ++v) {
+                    u64 c;
+                    if (nbv == 2) { c = (w[v >> 1] >> (16 * (v & 1))) & 0xffffu; if (!le) c = bswap16((uint32_t)c); }
+                    else if (nbv == 4) { c = w[v]; if (!le) c = bswap32((uint32_t)c); }
+                    else { c = (u64)w[2 * v] | ((u64)w[2 * v + 1] << 32); if (!le) c = bswap64(c); }
+                    xslot<double, SH>(smem, pi * vpp + v, slots, k) = code_to_f64(c, g.bits);
+                }
+            };
+            for (; p0 + 7 * T < pieces; p0 += 8 * T) {
+                uint32_t w[8][4];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int p = p0 + i * T, k = p / ppr, pi = p - k * ppr;
+                    load_words<4>(src + (long long)k * rowb + (long long)c0 * nbv + pi * 16, w[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) emit(p0 + i * T, w[i]);
+            }
+            for (int p = p0; p < pieces; p += T) {
+                const int k = p / ppr, pi = p - k * ppr;
+                uint32_t w[4];
+                load_words<4>(src + (long long)k * rowb + (long long)c0 * nbv + pi * 16, w);
+                emit(p, w);
+            }
+            return;
+        }
+    }
+    if (sized) {
+        // batches of 8 element loads in flight per lane
+        const int lgb = g.bits == 16 ? 1 : g.bits == 32 ? 2 : 3;
+        for (; q0 + 7 * T < total; q0 += 8 * T) {
+            u64 code[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int q = q0 + i * T, k = q / cgn, j = q - k * cgn;
+                code[i] = load_raw(src + (((long long)k * C + c0 + j) << lgb), lgb);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int q = q0 + i * T, k = q / cgn, j = q - k * cgn;
+                u64 c = code[i];
+                if (!le) c = lgb == 1 ? bswap16((uint32_t)c) : lgb == 2 ? bswap32((uint32_t)c) : bswap64(c);
+                xslot<double, SH>(smem, j, slots, k) = code_to_f64(c, g.bits);
+            }
+        }
+    }
+    for (int q = q0; q < total; q += T) {
         const int k = q / cgn, j = q - k * cgn;
         const long long idx = (long long)k * C + c0 + j;
         u64 code;
@@ -712,6 +789,15 @@ __device__ FRAD_NOINLINE void store_pcm_group(int smem_off, double* __restrict__
     unsigned char* smem = smem_base_ + smem_off;
     const int N = g.N, C = g.C;
     double* dst = out + f * (long long)N * C;
+    if ((cgn & 1) == 0 && (C & 1) == 0 && (c0 & 1) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        const int half = cgn / 2;                             // two channels = one 16-byte store
+        for (int q = threadIdx.x; q < N * half; q += blockDim.x) {
+            const int n = q / half, j = (q - n * half) * 2, m = makhoul(n, N);
+            v2d v = {xslot<double, SH>(smem, j, slots, m), xslot<double, SH>(smem, j + 1, slots, m)};
+            *FRAD_GPTR(v2d, dst + (long long)n * C + c0 + j) = v;
+        }
+        return;
+    }
     for (int q = threadIdx.x; q < N * cgn; q += blockDim.x) {
         const int n = q / cgn, j = q - n * cgn;
         dst[(long long)n * C + c0 + j] = xslot<double, SH>(smem, j, slots, makhoul(n, N));
