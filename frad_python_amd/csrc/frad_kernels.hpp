@@ -712,10 +712,11 @@ __device__ FRAD_NOINLINE void unpack_in_group(const unsigned char* __restrict__ 
     {
         // The group's share of a payload row (cgn values) is contiguous: when it is whole, aligned 16-byte pieces, a
         // lane loads a piece at a time, 8 pieces in flight -- one block per CU runs here, so only bytes in flight
-        // per lane hide the memory latency (element loads reach ~0.6 TB/s).
+        // per lane hide the memory latency (element loads reach ~0.6 TB/s).  64-bit values already move 8 bytes per
+        // element load and measured faster through the batched path below.
         const int nbv = g.bits >> 3;                          // bytes per value (16/32/64 bit)
         const long long rowb = (long long)C * nbv, pieceb = (long long)cgn * nbv;
-        if (sized && pieceb % 16 == 0 && rowb % 16 == 0 && ((long long)c0 * nbv) % 16 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        if (sized && nbv <= 4 && pieceb % 16 == 0 && rowb % 16 == 0 && ((long long)c0 * nbv) % 16 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
             const int ppr = (int)(pieceb / 16), vpp = 16 / nbv;          // pieces per row, values per piece
             const int pieces = N * ppr;
             int p0 = threadIdx.x;

@@ -164,6 +164,26 @@ def test_p0_any_length(be, fmt):
                 assert np.max(np.abs(dec[f] - ref[f][1])) <= 16 * EPS64 * max(np.log2(N), 1) * max(1.0, np.max(np.abs(ref[f][1])))
 
 
+def test_p0_frames_wider_than_a_cu(be):
+    """Frames whose float64 channels exceed the 160 KiB LDS go through channel groups; with exactly two groups
+    (cfg 4: N = 4096, C = 8) decode runs the whole-row two-pass kernel (k_p0_inv_grp2)."""
+    rng = np.random.default_rng(17)
+    shapes = _sizes(be, [(4096, 8, 1, (32,)), (4096, 6, 1, (16,))],
+                    [(4096, 8, 3, fo.DEPTHS), (4096, 6, 2, fo.DEPTHS), (2048, 16, 2, (16, 32, 64)), (8192, 4, 2, (16, 32, 64)),
+                     (16384, 2, 1, (32, 64)), (4096, 12, 2, (24, 32))])
+    for (N, C, F, depths) in shapes:
+        raw = synth.to_pcm(rng.uniform(-1, 1, (F * N, C)), "s16le")
+        for bits in depths:
+            for le in (False, True):
+                ref = oracle_frames(fo, 0, raw, "s16le", F, N, C, bits, le)
+                pay, am = be.analogue(0, raw, "s16le", F, N, C, bits, le)
+                for f in range(F):
+                    assert check_p0_payload(pay[f], ref[f][0], bits, le, "s16le", N) <= 2
+                dec = be.digital(0, np.stack([r[0] for r in ref]), F, N, C, bits, le)
+                for f in range(F):
+                    assert np.max(np.abs(dec[f] - ref[f][1])) <= 8 * EPS64 * np.log2(N)
+
+
 def test_overlapped_frame_gather(be):
     """frame_stride < N: the encoder's overlap read (encoder.py:35-51) as a strided gather."""
     rng = np.random.default_rng(16)
