@@ -557,9 +557,7 @@ __device__ __forceinline__ void unpack_in(const unsigned char* __restrict__ payl
     const int units = aligned ? NC / U : 0;
     for (int fl = 0; fl < nfl; ++fl) {
         const unsigned char* src = payload + (f0 + fl) * g.payload_stride;
-        for (int u = threadIdx.x; u < units; u += blockDim.x) {
-            uint32_t w[UB / 4];
-            load_words<UB / 4>(src + (long long)u * UB, w);
+        auto emit = [&](int u, const uint32_t (&w)[UB / 4]) {
             u64 codes[U];
             unpack_unit<BITS>(w, le, codes);
             int k = (u * U) / C, c = (u * U) - k * C;
@@ -568,6 +566,20 @@ __device__ __forceinline__ void unpack_in(const unsigned char* __restrict__ payl
                 xslot<double, SH>(smem, fl * C + c, slots, k) = code_to_f64(codes[i], BITS);
                 if (++c == C) { c = 0; ++k; }
             }
+        };
+        const int TH = blockDim.x;
+        int u = threadIdx.x;
+        for (; u + 3 * TH < units; u += 4 * TH) {            // four units in flight per lane before the first conversion
+            uint32_t w[4][UB / 4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) load_words<UB / 4>(src + (long long)(u + b * TH) * UB, w[b]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) emit(u + b * TH, w[b]);
+        }
+        for (; u < units; u += TH) {
+            uint32_t w[UB / 4];
+            load_words<UB / 4>(src + (long long)u * UB, w);
+            emit(u, w);
         }
         for (int i = units * U + threadIdx.x; i < NC; i += blockDim.x) {
             const int k = i / C, c = i - k * C;
