@@ -20,7 +20,7 @@ os.makedirs(dst, exist_ok=True)
 
 def one(pattern):
     g = glob.glob(os.path.join(src, pattern))
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None      # gpurun_out/ accumulates runs: take the newest
 
 
 stats = one(f"prof_{tag}_trace/*/*_kernel_stats.csv")
