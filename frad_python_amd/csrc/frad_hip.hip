@@ -412,7 +412,7 @@ int frad_p0_digital(const void* payload, int64_t payload_stride, int64_t n_frame
     if (c.ok) {
         Tables tb; rc = get_tables(c.log2m, false, tb);
         if (rc != FRAD_OK) return rc;
-        if (c.cg < C && bits == 12 && ((C & 1) || (c.cg & 1))) return FRAD_E_UNSUPPORTED;
+        // (12-bit pairs may straddle channel groups here: unpacking only reads them; the packing side refuses that)
         g.fpb = c.fpb; g.cg = c.cg;
         if (c.cg == C && ai && C <= 2 && ((long long)N * C) % 32 == 0) g.cc_fast = C;
         if (c.cg == C && C <= 2 && aligned16(pcm_out)) g.in_mode = C;      // decode: quad store for C = 1 / 2
