@@ -83,3 +83,37 @@ def test_random_geometries_against_oracle():
         done[_check(be, rng, profile, N, C, F, fmt, bits, le, offset, hop, pad, raw_be)] += 1
     print("fuzz:", rounds, "rounds", done)
     assert done["ok"] >= 0.65 * rounds, done
+
+
+def test_random_profile1_geometries_against_oracle():
+    """Profile 1 (K7 / K8) over random legal compact frame sizes, rates, depths, loss levels and channel counts."""
+    from frad_python_amd.fourier import profiles
+    from frad_python_amd._lib import FradError
+    from test_parity_p1 import _check_ints
+    be = GpuBackend()
+    rng = np.random.default_rng(int(os.environ.get("FRAD_FUZZ_SEED", "20261004")) + 1)
+    rounds = int(os.environ.get("FRAD_FUZZ_N", "220")) // 4
+    sizes = [n for n in profiles.compact.SAMPLES if n <= 8192]
+    dt = fo.pcm_dtype("s16le")
+    ok = refused = 0
+    for _ in range(rounds):
+        N = int(rng.choice(sizes)); C = int(rng.choice([1, 2, 2, 3, 6])); F = int(rng.choice([1, 2, 5]))
+        srate = int(rng.choice(profiles.compact.SRATES)); bits = int(rng.choice([8, 12, 16, 24, 32]))
+        loss = float(1.25 ** int(rng.integers(0, 21)) / 19.0 + 0.5)
+        raw = synth.to_pcm(synth.harmonic_mix(F * N, C, srate, seed=int(rng.integers(0, 1 << 30))) * rng.uniform(0.05, 1.0), "s16le")
+        try:
+            q, tq = be.p1_analogue(raw, "s16le", F, N, C, bits, srate, loss)
+        except FradError as e:
+            assert e.status == -2, (N, C, F, srate, bits, loss, str(e))
+            refused += 1
+            continue
+        for f in range(F):
+            wq, wt, aux = fo.p1_analogue_pre(fo.to_f64(raw[f * N:(f + 1) * N], dt), bits, srate, loss)
+            _check_ints(q[f].reshape(-1), wq, f"q {(N, C, srate, bits, loss, f)}")
+            _check_ints(tq[f].reshape(-1), wt, f"tq {(N, C, srate, bits, loss, f)}")
+            dec = be.p1_digital(wq.reshape(1, N, C).astype(np.int32), wt.reshape(1, 27, C).astype(np.int32), N, C, bits, srate)[0]
+            ref = fo.p1_digital_post(wq, wt, fo.P1_DEPTHS.index(bits), C, srate, N)
+            assert np.max(np.abs(dec - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref))), (N, C, srate, bits, loss, f)
+        ok += 1
+    print("p1 fuzz:", rounds, "rounds", {"ok": ok, "refused": refused})
+    assert ok >= 0.6 * rounds
