@@ -274,7 +274,7 @@ int frad_p4_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
     const long long NC = (long long)N * C;
     const int U = unit_values(bits);
     const bool fast = NC >= U && aligned16(pcm) && ((frame_stride * C) << lg) % 16 == 0 && aligned16(payload) && payload_stride % 16 == 0;
-    const int bpf = blocks_per_frame(fast ? NC / U : NC);
+    const int bpf = blocks_per_frame(fast ? (NC / U + 3) / 4 : NC);          // fast path: four units per thread
     if (n_frames * bpf > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
     dim3 grid((unsigned)(n_frames * bpf));
     const unsigned char* in = static_cast<const unsigned char*>(pcm);

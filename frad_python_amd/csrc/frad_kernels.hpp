@@ -94,22 +94,43 @@ __device__ __forceinline__ void p4_pack_body(const unsigned char* __restrict__ p
     unsigned char* dst = payload + f * g.payload_stride;
     const bool le = g.le && (BITS % 8 == 0);
     u64 mx = 0;
-    for (long long u = (long long)chunk * blockDim.x + threadIdx.x; u < units; u += (long long)bpf * blockDim.x) {
-        uint32_t w[NW];
-        if constexpr (RAWB >= 4) load_words<NW>(src + u * RAWB, w);
-        else w[0] = *reinterpret_cast<const unsigned short*>(src + u * RAWB);
-        u64 codes[U];
+    // the PCM format is resolved once (dispatch_pcm), not per element; four units are loaded before the first is
+    // converted so that 4 x RAWB bytes per lane are in flight
+    dispatch_pcm<LG>(g.dtype, g.raw_be, [&](auto code_tag, auto raw_tag) {
+        constexpr int CODE = decltype(code_tag)::value;
+        constexpr bool RAW = decltype(raw_tag)::value != 0;
+        auto load = [&](long long u, uint32_t (&w)[NW]) {
+            if constexpr (RAWB >= 4) load_words<NW>(src + u * RAWB, w);
+            else w[0] = *FRAD_GCPTR(unsigned short, src + u * RAWB);
+        };
+        auto emit = [&](long long u, const uint32_t (&w)[NW]) {
+            u64 codes[U];
 #pragma unroll
-        for (int i = 0; i < U; ++i) {
-            const T v = cvt_pcm<T>(word_elem<LG>(w, i), g.dtype, g.raw_be);
-            const u64 a = abs_bits((double)v);
-            mx = a > mx ? a : mx;
-            codes[i] = storage_code<T>(v, BITS);
+            for (int i = 0; i < U; ++i) {
+                const T v = cvt_pcm_c<T, CODE, RAW>(word_elem<LG>(w, i));
+                const u64 a = abs_bits((double)v);
+                mx = a > mx ? a : mx;
+                codes[i] = storage_code<T>(v, BITS);
+            }
+            uint32_t out[UB / 4];
+            pack_unit<BITS>(codes, le, out);
+            store_words<UB / 4>(dst + u * UB, out);
+        };
+        const long long step = (long long)bpf * blockDim.x;
+        long long u = (long long)chunk * blockDim.x + threadIdx.x;
+        for (; u + 3 * step < units; u += 4 * step) {
+            uint32_t w[4][NW];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) load(u + b * step, w[b]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) emit(u + b * step, w[b]);
         }
-        uint32_t out[UB / 4];
-        pack_unit<BITS>(codes, le, out);
-        store_words<UB / 4>(dst + u * UB, out);
-    }
+        for (; u < units; u += step) {
+            uint32_t w[NW];
+            load(u, w);
+            emit(u, w);
+        }
+    });
     const int tail = (int)(NC - units * U);
     if (tail && chunk == 0) {
         const long long first = units * U;
