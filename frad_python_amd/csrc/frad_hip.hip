@@ -306,11 +306,16 @@ int frad_p4_digital(const void* payload, int64_t payload_stride, int64_t n_frame
     const long long NC = (long long)N * C;
     const int U = unit_values(bits);
     const bool fast = NC >= U && aligned16(payload) && payload_stride % 16 == 0 && aligned16(pcm_out) && (NC % 2 == 0);
-    const int bpf = blocks_per_frame(fast ? NC / U : NC);
+    // 16 bit: a pair of values per thread keeps the float64 stores contiguous (4.0 -> 5.5 TB/s); at 32 bit the unit
+    // kernel is already at 5.7 TB/s and measured faster (`fast`: NC even, aligned rows)
+    const bool pairs = fast && bits == 16 && !getenv("FRAD_TUNE_NO_P4_PAIRS");
+    const int bpf = blocks_per_frame(pairs ? (NC / 2 + 3) / 4 : fast ? NC / U : NC);
     if (n_frames * bpf > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
     dim3 grid((unsigned)(n_frames * bpf));
     const unsigned char* in = static_cast<const unsigned char*>(payload);
-    if (fast) {
+    if (pairs) {
+        hipLaunchKernelGGL(k_p4_unpack_pairs<16>, grid, dim3(256), 0, s, in, pcm_out, g, bpf);
+    } else if (fast) {
         switch (bits) {
             case 12: hipLaunchKernelGGL(k_p4_unpack<12>, grid, dim3(256), 0, s, in, pcm_out, g, bpf); break;
             case 16: hipLaunchKernelGGL(k_p4_unpack<16>, grid, dim3(256), 0, s, in, pcm_out, g, bpf); break;

@@ -214,6 +214,45 @@ __global__ void __launch_bounds__(256) k_p4_unpack(const unsigned char* __restri
             dst[i] = code_to_f64(code_from_bytes(src, i, BITS, le), BITS);
 }
 
+// 16 / 32-bit depths: one thread = two values = one 16-byte output row, so that a wave's store instruction
+// writes 1 KiB of contiguous float64 (the unit kernel above stores 16 bytes out of every 64 / 32 per lane);
+// four pairs are loaded before the first is converted.
+template <int BITS>
+__global__ void __launch_bounds__(256) k_p4_unpack_pairs(const unsigned char* __restrict__ payload, double* __restrict__ out,
+                                                         Geom g, int bpf) {
+    static_assert(BITS == 16 || BITS == 32, "two values in one 4- or 8-byte load");
+    constexpr int NW = BITS / 16;                             // words per pair
+    const long long f = blockIdx.x / bpf;
+    const int chunk = blockIdx.x - (int)(f * bpf);
+    const long long NC = (long long)g.N * g.C, pairs = NC / 2;
+    const unsigned char* src = payload + f * g.payload_stride;
+    double* dst = out + f * NC;
+    const bool le = g.le != 0;
+    auto emit = [&](long long p, const uint32_t (&w)[NW]) {
+        u64 c0, c1;
+        if constexpr (BITS == 16) { c0 = w[0] & 0xffffu; c1 = w[0] >> 16; if (!le) { c0 = bswap16((uint32_t)c0); c1 = bswap16((uint32_t)c1); } }
+        else { c0 = w[0]; c1 = w[1]; if (!le) { c0 = bswap32((uint32_t)c0); c1 = bswap32((uint32_t)c1); } }
+        v2d v = {code_to_f64(c0, BITS), code_to_f64(c1, BITS)};
+        FRAD_GPTR(v2d, dst)[p] = v;
+    };
+    const long long step = (long long)bpf * blockDim.x;
+    long long p = (long long)chunk * blockDim.x + threadIdx.x;
+    for (; p + 3 * step < pairs; p += 4 * step) {
+        uint32_t w[4][NW];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) load_words<NW>(src + (p + b * step) * (NW * 4), w[b]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) emit(p + b * step, w[b]);
+    }
+    for (; p < pairs; p += step) {
+        uint32_t w[NW];
+        load_words<NW>(src + p * (NW * 4), w);
+        emit(p, w);
+    }
+    if (chunk == 0 && threadIdx.x == 0 && (NC & 1))
+        dst[NC - 1] = code_to_f64(code_from_bytes(src, NC - 1, BITS, le), BITS);
+}
+
 template <int UNUSED>
 __global__ void __launch_bounds__(256) k_p4_unpack_slow(const unsigned char* __restrict__ payload, double* __restrict__ out,
                                                         Geom g, int bpf) {
