@@ -309,12 +309,16 @@ int frad_p4_digital(const void* payload, int64_t payload_stride, int64_t n_frame
     // 16 bit: a pair of values per thread keeps the float64 stores contiguous (4.0 -> 5.5 TB/s); at 32 bit the unit
     // kernel is already at 5.7 TB/s and measured faster (`fast`: NC even, aligned rows)
     const bool pairs = fast && bits == 16 && !getenv("FRAD_TUNE_NO_P4_PAIRS");
-    const int bpf = blocks_per_frame(pairs ? (NC / 2 + 3) / 4 : fast ? NC / U : NC);
+    const bool sub12 = fast && (bits == 24 || bits == 48) && !getenv("FRAD_TUNE_NO_P4_PAIRS");   // same idea, 12-byte sub-units
+    const int bpf = blocks_per_frame(pairs ? (NC / 2 + 3) / 4 : sub12 ? (NC / (96 / bits) + 3) / 4 : fast ? NC / U : NC);
     if (n_frames * bpf > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
     dim3 grid((unsigned)(n_frames * bpf));
     const unsigned char* in = static_cast<const unsigned char*>(payload);
     if (pairs) {
         hipLaunchKernelGGL(k_p4_unpack_pairs<16>, grid, dim3(256), 0, s, in, pcm_out, g, bpf);
+    } else if (sub12) {
+        if (bits == 24) hipLaunchKernelGGL(k_p4_unpack_12b<24>, grid, dim3(256), 0, s, in, pcm_out, g, bpf);
+        else hipLaunchKernelGGL(k_p4_unpack_12b<48>, grid, dim3(256), 0, s, in, pcm_out, g, bpf);
     } else if (fast) {
         switch (bits) {
             case 12: hipLaunchKernelGGL(k_p4_unpack<12>, grid, dim3(256), 0, s, in, pcm_out, g, bpf); break;

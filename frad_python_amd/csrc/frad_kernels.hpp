@@ -48,6 +48,9 @@ template <int NW> __device__ __forceinline__ void load_words(const unsigned char
             const v4u v = FRAD_GCPTR(v4u, p)[i];
             w[4 * i] = v[0]; w[4 * i + 1] = v[1]; w[4 * i + 2] = v[2]; w[4 * i + 3] = v[3];
         }
+    } else if constexpr (NW == 3) {                           // 12 bytes, 4-byte aligned (24- / 48-bit sub-units)
+        const auto* q = FRAD_GCPTR(uint32_t, p);
+        w[0] = q[0]; w[1] = q[1]; w[2] = q[2];
     } else if constexpr (NW == 2) {
         const v2u v = *FRAD_GCPTR(v2u, p); w[0] = v[0]; w[1] = v[1];
     } else {
@@ -251,6 +254,54 @@ __global__ void __launch_bounds__(256) k_p4_unpack_pairs(const unsigned char* __
     }
     if (chunk == 0 && threadIdx.x == 0 && (NC & 1))
         dst[NC - 1] = code_to_f64(code_from_bytes(src, NC - 1, BITS, le), BITS);
+}
+
+// 24 / 48-bit depths: one thread = 12 payload bytes = 4 / 2 values, i.e. 32 / 16 contiguous output bytes per lane
+// (the 48-byte unit kernel above leaves 128-byte gaps between a lane's stores); four loads in flight per lane.
+template <int BITS>
+__global__ void __launch_bounds__(256) k_p4_unpack_12b(const unsigned char* __restrict__ payload, double* __restrict__ out,
+                                                       Geom g, int bpf) {
+    static_assert(BITS == 24 || BITS == 48, "12-byte sub-units");
+    constexpr int NB = BITS / 8, V = 12 / NB;
+    const long long f = blockIdx.x / bpf;
+    const int chunk = blockIdx.x - (int)(f * bpf);
+    const long long NC = (long long)g.N * g.C, subs = NC / V;
+    const unsigned char* src = payload + f * g.payload_stride;
+    double* dst = out + f * NC;
+    const bool le = g.le != 0;
+    auto emit = [&](long long u, const uint32_t (&w)[3]) {
+        double val[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            u64 c = 0;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int s = i * NB + j;
+                const u64 b = (w[s >> 2] >> (8 * (s & 3))) & 0xffu;
+                c |= b << (le ? 8 * j : 8 * (NB - 1 - j));
+            }
+            val[i] = code_to_f64(c, BITS);
+        }
+#pragma unroll
+        for (int i = 0; i < V / 2; ++i) { v2d v = {val[2 * i], val[2 * i + 1]}; FRAD_GPTR(v2d, dst + u * V)[i] = v; }
+    };
+    const long long step = (long long)bpf * blockDim.x;
+    long long u = (long long)chunk * blockDim.x + threadIdx.x;
+    for (; u + 3 * step < subs; u += 4 * step) {
+        uint32_t w[4][3];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) load_words<3>(src + (u + b * step) * 12, w[b]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) emit(u + b * step, w[b]);
+    }
+    for (; u < subs; u += step) {
+        uint32_t w[3];
+        load_words<3>(src + u * 12, w);
+        emit(u, w);
+    }
+    if (chunk == 0)
+        for (long long i = subs * V + threadIdx.x; i < NC; i += blockDim.x)
+            dst[i] = code_to_f64(code_from_bytes(src, i, BITS, le), BITS);
 }
 
 template <int UNUSED>
