@@ -343,10 +343,9 @@ __device__ FRAD_NOINLINE void stage_in_pcm(const unsigned char* __restrict__ pcm
     if (aligned) {
         constexpr int EPC = 16 >> LG;                 // elements per 16-byte chunk
         const int chunks = (NC + EPC - 1) / EPC;      // NC * itemsize is a multiple of 16 here
-        for (int q = threadIdx.x; q < nfl * chunks; q += blockDim.x) {
+        auto fetch = [&](int q, uint32_t (&w)[4]) {
             const int fl = q / chunks, ch = q - fl * chunks;
             const unsigned char* src = pcm + (((f0 + fl) * g.frame_stride * C) << LG);
-            uint32_t w[4];
             const int e0 = ch * EPC;
             if (e0 + EPC <= nv) load_words<4>(src + ((long long)e0 << LG), w);
             else {
@@ -359,6 +358,10 @@ __device__ FRAD_NOINLINE void stage_in_pcm(const unsigned char* __restrict__ pcm
                     else w[i >> 2] |= (uint32_t)r << (8 * (i & 3));
                 }
             }
+        };
+        auto place = [&](int q, const uint32_t (&w)[4]) {
+            const int fl = q / chunks, ch = q - fl * chunks;
+            const int e0 = ch * EPC;
             int n = e0 / C, c = e0 - n * C;
 #pragma unroll
             for (int i = 0; i < EPC; ++i) {
@@ -369,6 +372,20 @@ __device__ FRAD_NOINLINE void stage_in_pcm(const unsigned char* __restrict__ pcm
                 }
                 if (++c == C) { c = 0; ++n; }
             }
+        };
+        const int total = nfl * chunks, TH = blockDim.x;
+        int q = threadIdx.x;
+        for (; q + 3 * TH < total; q += 4 * TH) {            // four 16-byte chunks in flight per lane
+            uint32_t w[4][4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fetch(q + b * TH, w[b]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) place(q + b * TH, w[b]);
+        }
+        for (; q < total; q += TH) {
+            uint32_t w[4];
+            fetch(q, w);
+            place(q, w);
         }
     } else {
         for (int q = threadIdx.x; q < nfl * NC; q += blockDim.x) {
