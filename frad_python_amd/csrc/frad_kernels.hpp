@@ -551,16 +551,22 @@ __device__ __forceinline__ void unpack_in_pairs(const unsigned char* __restrict_
     constexpr int V = U > 2 * CC ? U : 2 * CC, KB = V / CC;
     const bool le = g.le && (BITS % 8 == 0);
     const int tasks = (g.N * CC) / V;
-    for (int q = threadIdx.x; q < nfl * tasks; q += blockDim.x) {
+    constexpr int WPT = (V / U) * (UB / 4);                   // words per task
+    auto fetch = [&](int q, uint32_t (&in)[WPT]) {
         const int fl = q / tasks, u = q - fl * tasks;
         const unsigned char* src = payload + (f0 + fl) * g.payload_stride;
+        load_words<WPT>(src + (long long)u * (V / U) * UB, in);
+    };
+    auto place = [&](int q, const uint32_t (&in)[WPT]) {
+        const int fl = q / tasks, u = q - fl * tasks;
         u64 codes[V];
 #pragma unroll
         for (int w = 0; w < V / U; ++w) {
-            uint32_t in[UB / 4];
-            load_words<UB / 4>(src + ((long long)u * (V / U) + w) * UB, in);
+            uint32_t part[UB / 4];
+#pragma unroll
+            for (int i = 0; i < UB / 4; ++i) part[i] = in[w * (UB / 4) + i];
             u64 unit[U];
-            unpack_unit<BITS>(in, le, unit);
+            unpack_unit<BITS>(part, le, unit);
 #pragma unroll
             for (int i = 0; i < U; ++i) codes[w * U + i] = unit[i];
         }
@@ -573,6 +579,22 @@ __device__ __forceinline__ void unpack_in_pairs(const unsigned char* __restrict_
                 buf[phys<double, SH>(s0 + kk)] = cx<double>{code_to_f64(codes[(2 * kk) * CC + c], BITS),
                                                             code_to_f64(codes[(2 * kk + 1) * CC + c], BITS)};
         }
+    };
+    const int total = nfl * tasks, TH = blockDim.x;
+    int q = threadIdx.x;
+    if constexpr (WPT <= 8) {                                 // up to 32 bytes per task: four tasks in flight per lane
+        for (; q + 3 * TH < total; q += 4 * TH) {
+            uint32_t in[4][WPT];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fetch(q + b * TH, in[b]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) place(q + b * TH, in[b]);
+        }
+    }
+    for (; q < total; q += TH) {
+        uint32_t in[WPT];
+        fetch(q, in);
+        place(q, in);
     }
 }
 template <int SH, int CC>
