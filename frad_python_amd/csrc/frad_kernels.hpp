@@ -411,25 +411,45 @@ __device__ __forceinline__ void stage_in_quads_small(const unsigned char* __rest
     static_assert(GPC >= 1, "row must divide 4 rows into 16 bytes");
     const int M = g.N >> 1;
     const int chunks = (g.N * C) / EPC;
-    for (int q = threadIdx.x; q < nfl * chunks; q += blockDim.x) {
-        const int fl = q / chunks, ch = q - fl * chunks;
-        const unsigned char* src = pcm + (((f0 + fl) * g.frame_stride * C) << LG);
-        uint32_t w[4];
-        load_words<4>(src + (long long)ch * 16, w);
+    // format resolved once (dispatch_pcm); four 16-byte chunks in flight per lane
+    dispatch_pcm<LG>(g.dtype, g.raw_be, [&](auto code_tag, auto raw_tag) {
+        constexpr int CODE = decltype(code_tag)::value;
+        constexpr bool RAW = decltype(raw_tag)::value != 0;
+        auto fetch = [&](int q, uint32_t (&w)[4]) {
+            const int fl = q / chunks, ch = q - fl * chunks;
+            load_words<4>(pcm + (((f0 + fl) * g.frame_stride * C) << LG) + (long long)ch * 16, w);
+        };
+        auto place = [&](int q, const uint32_t (&w)[4]) {
+            const int fl = q / chunks, ch = q - fl * chunks;
 #pragma unroll
-        for (int gi = 0; gi < GPC; ++gi) {
-            const int zq = ch * GPC + gi;
+            for (int gi = 0; gi < GPC; ++gi) {
+                const int zq = ch * GPC + gi;
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                cx<T>* buf = reinterpret_cast<cx<T>*>(smem) + (long long)(fl * C + c) * slots;
-                T e[4];
+                for (int c = 0; c < C; ++c) {
+                    cx<T>* buf = reinterpret_cast<cx<T>*>(smem) + (long long)(fl * C + c) * slots;
+                    T e[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) e[i] = cvt_pcm<T>(word_elem<LG>(w, (gi * 4 + i) * C + c), g.dtype, g.raw_be);
-                buf[phys<T, SH>(zq)] = cx<T>{e[0], e[2]};
-                buf[phys<T, SH>(M - 1 - zq)] = cx<T>{e[3], e[1]};
+                    for (int i = 0; i < 4; ++i) e[i] = cvt_pcm_c<T, CODE, RAW>(word_elem<LG>(w, (gi * 4 + i) * C + c));
+                    buf[phys<T, SH>(zq)] = cx<T>{e[0], e[2]};
+                    buf[phys<T, SH>(M - 1 - zq)] = cx<T>{e[3], e[1]};
+                }
             }
+        };
+        const int total = nfl * chunks, TH = blockDim.x;
+        int q = threadIdx.x;
+        for (; q + 3 * TH < total; q += 4 * TH) {
+            uint32_t w[4][4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fetch(q + b * TH, w[b]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) place(q + b * TH, w[b]);
         }
-    }
+        for (; q < total; q += TH) {
+            uint32_t w[4];
+            fetch(q, w);
+            place(q, w);
+        }
+    });
 }
 
 template <typename T, int LG, int SH>

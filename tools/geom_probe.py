@@ -10,7 +10,8 @@ def timeit(fn, n=10):
     b.record(); torch.cuda.synchronize(); return a.elapsed_time(b) / n
 g = torch.Generator(device=dev).manual_seed(1)
 S = 2812 * 4096 * 8
-for (N, C, fmt, bits) in [(4096, 8, "f32le", 32), (2048, 8, "f32le", 32), (4096, 4, "f32le", 32), (4096, 2, "f32le", 32), (2048, 2, "f32le", 32), (8192, 8, "f32le", 32), (4096, 8, "s16le", 16), (4096, 8, "s32le", 64)]:
+for (N, C, fmt, bits) in [(4096, 8, "f32le", 32), (2048, 8, "f32le", 32), (4096, 4, "f32le", 32), (4096, 2, "f32le", 32), (2048, 2, "f32le", 32), (8192, 8, "f32le", 32), (4096, 8, "s16le", 16), (4096, 8, "s32le", 64),
+                          (4096, 2, "s16le", 32), (1024, 2, "s16le", 32), (8192, 2, "s16le", 32), (512, 2, "s16le", 32), (2048, 1, "s16le", 32), (2048, 6, "s16le", 24)]:
     F = S // (N * C)
     if fmt == "f32le": pcm = (torch.rand((F * N, C), generator=g, device=dev) * 1.8 - 0.9).to(torch.float32)
     elif fmt == "s16le": pcm = (torch.randn((F * N, C), generator=g, device=dev) * 8000).clamp(-32768, 32767).to(torch.int16)
