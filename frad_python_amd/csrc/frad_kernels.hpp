@@ -359,34 +359,38 @@ __device__ FRAD_NOINLINE void stage_in_pcm(const unsigned char* __restrict__ pcm
                 }
             }
         };
-        auto place = [&](int q, const uint32_t (&w)[4]) {
-            const int fl = q / chunks, ch = q - fl * chunks;
-            const int e0 = ch * EPC;
-            int n = e0 / C, c = e0 - n * C;
-#pragma unroll
-            for (int i = 0; i < EPC; ++i) {
-                const int e = e0 + i;
-                if (e < NC) {
-                    const T v = e < nv ? cvt_pcm<T>(word_elem<LG>(w, i), g.dtype, g.raw_be) : (T)0;
-                    xslot<T, SH>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n) = v;
-                }
-                if (++c == C) { c = 0; ++n; }
-            }
-        };
         const int total = nfl * chunks, TH = blockDim.x;
-        int q = threadIdx.x;
-        for (; q + 3 * TH < total; q += 4 * TH) {            // four 16-byte chunks in flight per lane
-            uint32_t w[4][4];
+        dispatch_pcm<LG>(g.dtype, g.raw_be, [&](auto code_tag, auto raw_tag) {      // format resolved once, not per element
+            constexpr int CODE = decltype(code_tag)::value;
+            constexpr bool RAW = decltype(raw_tag)::value != 0;
+            auto place_c = [&](int q, const uint32_t (&w)[4]) {
+                const int fl = q / chunks, ch = q - fl * chunks;
+                const int e0 = ch * EPC;
+                int n = e0 / C, c = e0 - n * C;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) fetch(q + b * TH, w[b]);
+                for (int i = 0; i < EPC; ++i) {
+                    const int e = e0 + i;
+                    if (e < NC) {
+                        const T v = e < nv ? cvt_pcm_c<T, CODE, RAW>(word_elem<LG>(w, i)) : (T)0;
+                        xslot<T, SH>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n) = v;
+                    }
+                    if (++c == C) { c = 0; ++n; }
+                }
+            };
+            int q = threadIdx.x;
+            for (; q + 3 * TH < total; q += 4 * TH) {        // four 16-byte chunks in flight per lane
+                uint32_t w[4][4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) place(q + b * TH, w[b]);
-        }
-        for (; q < total; q += TH) {
-            uint32_t w[4];
-            fetch(q, w);
-            place(q, w);
-        }
+                for (int b = 0; b < 4; ++b) fetch(q + b * TH, w[b]);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) place_c(q + b * TH, w[b]);
+            }
+            for (; q < total; q += TH) {
+                uint32_t w[4];
+                fetch(q, w);
+                place_c(q, w);
+            }
+        });
     } else {
         for (int q = threadIdx.x; q < nfl * NC; q += blockDim.x) {
             const int fl = q / NC, e = q - fl * NC;
