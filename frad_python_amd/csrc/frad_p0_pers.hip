@@ -55,27 +55,27 @@ void go_inv_bits(const void* blob, int cc, int threads, size_t lds, int grid, hi
         default: go_inv<PL, MAXT, 64>(blob, cc, threads, lds, grid, s, pay, out, g, ngroups); break;
     }
 }
-template <int LG>
+template <int LG, typename PL = PlanA10>
 void go_fwd_unit(const void* blob, int cc, size_t lds, int grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay,
                  double* am, const Geom& g) {
     const cx<double>* b = static_cast<const cx<double>*>(blob);
     if (cc == 2) {
-        allow_lds(k_p0_fwd_unit<double, PlanA10, LG, 2>, lds);
-        hipLaunchKernelGGL((k_p0_fwd_unit<double, PlanA10, LG, 2>), dim3(grid), dim3(512), lds, s, pcm, pay, am, b, g);
+        allow_lds(k_p0_fwd_unit<double, PL, LG, 2>, lds);
+        hipLaunchKernelGGL((k_p0_fwd_unit<double, PL, LG, 2>), dim3(grid), dim3(512), lds, s, pcm, pay, am, b, g);
     } else {
-        allow_lds(k_p0_fwd_unit<double, PlanA10, LG, 1>, lds);
-        hipLaunchKernelGGL((k_p0_fwd_unit<double, PlanA10, LG, 1>), dim3(grid), dim3(512), lds, s, pcm, pay, am, b, g);
+        allow_lds(k_p0_fwd_unit<double, PL, LG, 1>, lds);
+        hipLaunchKernelGGL((k_p0_fwd_unit<double, PL, LG, 1>), dim3(grid), dim3(512), lds, s, pcm, pay, am, b, g);
     }
 }
-template <int BITS>
+template <int BITS, typename PL = PlanA10>
 void go_inv_unit_a(const void* blob, int cc, size_t lds, int grid, hipStream_t s, const unsigned char* pay, double* out, const Geom& g) {
     const cx<double>* b = static_cast<const cx<double>*>(blob);
     if (cc == 2) {
-        allow_lds(k_p0_inv_unit<PlanA10, BITS, 2>, lds);
-        hipLaunchKernelGGL((k_p0_inv_unit<PlanA10, BITS, 2>), dim3(grid), dim3(512), lds, s, pay, out, b, g);
+        allow_lds(k_p0_inv_unit<PL, BITS, 2>, lds);
+        hipLaunchKernelGGL((k_p0_inv_unit<PL, BITS, 2>), dim3(grid), dim3(512), lds, s, pay, out, b, g);
     } else {
-        allow_lds(k_p0_inv_unit<PlanA10, BITS, 1>, lds);
-        hipLaunchKernelGGL((k_p0_inv_unit<PlanA10, BITS, 1>), dim3(grid), dim3(512), lds, s, pay, out, b, g);
+        allow_lds(k_p0_inv_unit<PL, BITS, 1>, lds);
+        hipLaunchKernelGGL((k_p0_inv_unit<PL, BITS, 1>), dim3(grid), dim3(512), lds, s, pay, out, b, g);
     }
 }
 // default: the unfused 16-16-4 inverse (plan A).  FRAD_TUNE_INV_PLAN=I selects the 4-16-16 plan with the pair step
@@ -139,6 +139,7 @@ size_t pers_blob_build(int log2m, bool f32, int which, std::vector<unsigned char
         else fill_blob<double, PlanI10>(bytes, unit);
     }
     else if (log2m == 11 && f32 && which == 0) fill_blob<float, PlanA11>(bytes, unit);
+    else if (log2m == 9 && !f32 && which == 0) fill_blob<double, PlanA9>(bytes, unit);
     return bytes.size();
 }
 
@@ -146,20 +147,32 @@ size_t pers_blob_build(int log2m, bool f32, int which, std::vector<unsigned char
 int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const unsigned char* pcm, unsigned char* pay,
                        double* am, const Tables& tb, Geom g, int ao) {
     if (disabled() || tb.blob == nullptr || c.cg != g.C || g.in_mode == 0 || g.n_valid != g.N || g.C > 8) return 0;
-    const bool geom_ok = f32 ? (c.log2m == 11 && lg == 2) : (c.log2m == 10 && lg >= 1 && lg <= 3);
+    const bool n1024 = !f32 && c.log2m == 9 && lg >= 1 && lg <= 3 && g.bits != 12 && !getenv("FRAD_TUNE_NO_UNIT9");
+    const bool geom_ok = f32 ? (c.log2m == 11 && lg == 2) : ((c.log2m == 10 && lg >= 1 && lg <= 3) || n1024);
     if (!geom_ok) return 0;
     if (!f32 && unit_sync() && !plan_b() && g.C <= 2 && g.cc_fast == g.C &&
         ((g.in_mode == 1) || (g.in_mode == 2 && (8 >> lg) == g.C) || (g.in_mode == 3 && lg >= (g.C == 1 ? 4 : 3)))) {
         // unit-synchronised kernel: one frame per unit of C waves, 8 / C units per block
         const int upb = 8 / g.C;
+        const long long nb = (g.n_frames + upb - 1) / upb;
+        if (n1024) {                                          // 8 KiB per channel-frame: two blocks per CU
+            const size_t lds = (size_t)pers_table_bytes<double, PlanA9>() + 128 + 8 * 512 * 16;
+            const long long cap = (long long)cu_count() * 2;
+            const int grid = (int)(nb < cap ? nb : cap);
+            if (lg == 1) go_fwd_unit<1, PlanA9>(tb.blob, g.C, lds, grid, s, pcm, pay, am, g);
+            else if (lg == 2) go_fwd_unit<2, PlanA9>(tb.blob, g.C, lds, grid, s, pcm, pay, am, g);
+            else go_fwd_unit<3, PlanA9>(tb.blob, g.C, lds, grid, s, pcm, pay, am, g);
+            return 1;
+        }
         const size_t lds = (size_t)pers_table_bytes<double, PlanA10>() + 128 + 8 * 1024 * 16;
-        const long long nb = (g.n_frames + upb - 1) / upb, cap = (long long)cu_count() * blocks_per_cu();
+        const long long cap = (long long)cu_count() * blocks_per_cu();
         const int grid = (int)(nb < cap ? nb : cap);
         if (lg == 1) go_fwd_unit<1>(tb.blob, g.C, lds, grid, s, pcm, pay, am, g);
         else if (lg == 2) go_fwd_unit<2>(tb.blob, g.C, lds, grid, s, pcm, pay, am, g);
         else go_fwd_unit<3>(tb.blob, g.C, lds, grid, s, pcm, pay, am, g);
         return 1;
     }
+    if (n1024) return 0;                                      // the block-barrier variant is not built for N = 1024
     if (am != nullptr && hipMemsetAsync(am, 0, sizeof(double) * (size_t)g.n_frames, s) != hipSuccess) return 0;
     const bool pb = !f32 && plan_b() && tb.blob_b != nullptr && lg <= 2;
     const int team = f32 ? PlanA11::TEAM : pb ? PlanB10::TEAM : PlanA10::TEAM, M = 1 << c.log2m;
@@ -187,7 +200,22 @@ int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const 
 }
 
 int launch_p0_inv_pers(const FastCfg& c, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb, Geom g) {
-    if (disabled() || tb.blob == nullptr || c.cg != g.C || c.log2m != 10 || g.C > 2 || g.cc_fast != g.C || g.in_mode != g.C) return 0;
+    if (disabled() || tb.blob == nullptr || c.cg != g.C || (c.log2m != 10 && c.log2m != 9) || g.C > 2 || g.cc_fast != g.C || g.in_mode != g.C) return 0;
+    if (c.log2m == 9) {                                       // N = 1024: unit kernel only, two blocks per CU
+        if (!unit_sync() || plan_b() || g.bits == 12 || getenv("FRAD_TUNE_NO_UNIT9")) return 0;
+        const int upb = 8 / g.C;
+        const size_t lds = (size_t)pers_table_bytes<double, PlanA9>() + 32 + 8 * 512 * 16;
+        const long long nb = (g.n_frames + upb - 1) / upb, cap = (long long)cu_count() * 2;
+        const int grid = (int)(nb < cap ? nb : cap);
+        switch (g.bits) {
+            case 16: go_inv_unit_a<16, PlanA9>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+            case 24: go_inv_unit_a<24, PlanA9>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+            case 32: go_inv_unit_a<32, PlanA9>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+            case 48: go_inv_unit_a<48, PlanA9>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+            default: go_inv_unit_a<64, PlanA9>(tb.blob, g.C, lds, grid, s, pay, out, g); break;
+        }
+        return 1;
+    }
     if (unit_sync() && !plan_b() && inv_plan_a()) {
         const int upb = 8 / g.C;
         const size_t lds = (size_t)pers_table_bytes<double, PlanA10>() + 32 + 8 * 1024 * 16;

@@ -25,7 +25,11 @@ namespace frad {
 struct PlanA10 { static constexpr int LOG2M = 10, TEAM = 64,  SH = 4, R1 = 16, R2 = 16, R3 = 4, R4 = 0; };  // 2 waves/SIMD
 struct PlanB10 { static constexpr int LOG2M = 10, TEAM = 128, SH = 3, R1 = 8,  R2 = 8,  R3 = 8, R4 = 2; };  // 4 waves/SIMD
 struct PlanI10 { static constexpr int LOG2M = 10, TEAM = 64,  SH = 100, R1 = 4, R2 = 16, R3 = 16, R4 = 0; };  // inverse, fused first pass
+struct PlanA9  { static constexpr int LOG2M = 9,  TEAM = 64,  SH = 3, R1 = 8,  R2 = 8,  R3 = 8, R4 = 0; };   // N = 1024: two blocks per CU
 struct PlanA11 { static constexpr int LOG2M = 11, TEAM = 64,  SH = 4, R1 = 16, R2 = 16, R3 = 8, R4 = 0; };
+
+// resident waves per SIMD the unit kernels are compiled for: N = 1024 (8 KiB per channel-frame) lets two blocks share a CU
+template <typename PL> struct UnitWaves { static constexpr int value = PL::LOG2M <= 9 ? 4 : 2; };
 
 // LDS table blob of a plan (units: complex slots): [pass-2][pass-3][pass-4 tables][w_k][g_k]
 template <typename PL> struct PersLayout {
@@ -489,7 +493,7 @@ __device__ __forceinline__ u64 pack_frame_pairs(const unsigned char* data, unsig
     constexpr int U = unit_values(BITS), UB = unit_bytes(BITS);
     constexpr int V = U > 2 * CC ? U : 2 * CC, KB = V / CC;
     constexpr int tasks = (2 * M * CC) / V, uth = CC * 64, ITER = tasks / uth;
-    static_assert(ITER * uth == tasks, "whole tasks per lane");
+    if constexpr (ITER * uth != tasks) return 0;             // a 12-bit unit is wider than a lane's share at N = 1024: the host never selects it
     double fm = 0.0;
     bool nan = false;
     // compile-time trip count: the LDS reads of several tasks are in flight before the first conversion
@@ -543,7 +547,7 @@ __device__ FRAD_NOINLINE void pack_frame_pairs_any(int data_off, unsigned char* 
 }
 
 template <typename T, typename PL, int LG, int CC>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(512, UnitWaves<PL>::value)
 k_p0_fwd_unit(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload, double* absmax,
               const cx<T>* __restrict__ blob, Geom g) {
     constexpr int LOG2M = PL::LOG2M, M = 1 << LOG2M, N = 2 * M, TEAM = PL::TEAM, SH = PL::SH;
@@ -656,7 +660,12 @@ k_p0_fwd_unit(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         cx<T>* buf = reinterpret_cast<cx<T>*>(data) + co;
         fft_pass_lt<T, M, TEAM, PL::R1, 1, false, SH>(buf, t, ltab);
         fft_pass_lt<T, M, TEAM, PL::R2, PersLayout<PL>::NS2, false, SH>(buf, t, ltab + PersLayout<PL>::OFF2);
-        fft_last_pass_dct<T, PL>(buf, t, ltab, lpost, deferred);
+        if constexpr (M == 1024) {
+            fft_last_pass_dct<T, PL>(buf, t, ltab, lpost, deferred);
+        } else {                                              // other sizes: last pass and DCT pair step through LDS
+            fft_pass_lt<T, M, TEAM, PL::R3, PersLayout<PL>::NS3, false, SH>(buf, t, ltab + PersLayout<PL>::OFF3);
+            dct_post<T, LOG2M, 1, TEAM, SH, true>(buf, t, lpost, deferred);
+        }
 #pragma unroll
         for (int i = 0; i < CPT; ++i)
 #pragma unroll
@@ -707,7 +716,7 @@ __device__ FRAD_NOINLINE void store_frame_rows(int data_off, double* __restrict_
 }
 
 template <typename PL, int BITS, int CC>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(512, UnitWaves<PL>::value)
 k_p0_inv_unit(const unsigned char* __restrict__ payload, double* __restrict__ out, const cx<double>* __restrict__ blob, Geom g) {
     constexpr int LOG2M = PL::LOG2M, M = 1 << LOG2M, N = 2 * M, TEAM = PL::TEAM, SH = PL::SH;
     static_assert(TEAM == 64, "one wave per channel-frame");

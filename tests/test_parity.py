@@ -100,8 +100,8 @@ def test_p4_unaligned_buffers_and_strides(be):
 @pytest.mark.parametrize("fmt", ["s16le", "f64le", "f32le"])
 def test_p0_fft_sizes(be, fmt):
     rng = np.random.default_rng(13)
-    shapes = _sizes(be, [(2048, 2, 3), (128, 1, 5), (256, 3, 2), (512, 2, 2), (1024, 1, 2), (4096, 2, 1), (512, 20, 1), (2048, 2, 19), (2048, 1, 9)],
-                    [(2048, 2, 9), (128, 1, 5), (256, 3, 4), (512, 2, 4), (1024, 1, 3), (4096, 2, 3), (4096, 8, 3),
+    shapes = _sizes(be, [(2048, 2, 3), (128, 1, 5), (256, 3, 2), (512, 2, 2), (1024, 1, 2), (1024, 2, 9), (4096, 2, 1), (512, 20, 1), (2048, 2, 19), (2048, 1, 9)],
+                    [(2048, 2, 9), (128, 1, 5), (256, 3, 4), (512, 2, 4), (1024, 1, 3), (1024, 2, 2063), (1024, 1, 1031), (4096, 2, 3), (4096, 8, 3),
                      (8192, 1, 2), (16384, 1, 2), (2048, 8, 3), (128, 5, 3), (2048, 1, 5), (512, 20, 2), (1024, 18, 2), (2048, 2, 1031), (2048, 1, 517), (4096, 2, 300)])
     for (N, C, F) in shapes:
         if not fits_lds(N, C, fmt):
