@@ -156,7 +156,7 @@ int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const 
         const int upb = 8 / g.C;
         const long long nb = (g.n_frames + upb - 1) / upb;
         if (n1024) {                                          // 8 KiB per channel-frame: two blocks per CU
-            const size_t lds = (size_t)pers_table_bytes<double, PlanA9>() + 128 + 8 * 512 * 16;
+            const size_t lds = (size_t)pers_table_bytes<double, PlanA9>() + 96 + 8 * 512 * 16;     // 2 x 81 920 B = the whole LDS
             const long long cap = (long long)cu_count() * 2;
             const int grid = (int)(nb < cap ? nb : cap);
             if (lg == 1) go_fwd_unit<1, PlanA9>(tb.blob, g.C, lds, grid, s, pcm, pay, am, g);
@@ -164,7 +164,7 @@ int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const 
             else go_fwd_unit<3, PlanA9>(tb.blob, g.C, lds, grid, s, pcm, pay, am, g);
             return 1;
         }
-        const size_t lds = (size_t)pers_table_bytes<double, PlanA10>() + 128 + 8 * 1024 * 16;
+        const size_t lds = (size_t)pers_table_bytes<double, PlanA10>() + 96 + 8 * 1024 * 16;
         const long long cap = (long long)cu_count() * blocks_per_cu();
         const int grid = (int)(nb < cap ? nb : cap);
         if (lg == 1) go_fwd_unit<1>(tb.blob, g.C, lds, grid, s, pcm, pay, am, g);

@@ -552,13 +552,13 @@ k_p0_fwd_unit(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
               const cx<T>* __restrict__ blob, Geom g) {
     constexpr int LOG2M = PL::LOG2M, M = 1 << LOG2M, N = 2 * M, TEAM = PL::TEAM, SH = PL::SH;
     static_assert(TEAM == 64, "one wave per channel-frame");
-    constexpr int TB = pers_table_bytes<T, PL>(), CTRB = 128;    // 16 barrier words + 8 per-wave |X| maxima
+    constexpr int TB = pers_table_bytes<T, PL>(), CTRB = 96;     // 8 barrier words + 8 per-wave |X| maxima (N = 1024: two blocks fit 160 KiB)
     constexpr int CPT = (N << LG) / (16 * TEAM), EPC = 16 >> LG;
     constexpr int UTH = CC * 64, UPB = 8 / CC;               // threads per unit, units per block
     FRAD_DYN_SMEM(smem);
     pers_load_tables<T, PL>(smem, blob);
     unsigned* ctrs = reinterpret_cast<unsigned*>(smem + TB);
-    if (threadIdx.x < 16) ctrs[threadIdx.x] = 0;
+    if (threadIdx.x < 8) ctrs[threadIdx.x] = 0;
     const cx<T>* ltab = reinterpret_cast<const cx<T>*>(smem);
     const cx<T>* lpost = ltab + PersLayout<PL>::OFFP;
     const int unit = threadIdx.x / UTH, utid0 = threadIdx.x - unit * UTH;
@@ -671,10 +671,10 @@ k_p0_fwd_unit(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
 #pragma unroll
             for (int j = 0; j < 4; ++j) FRAD_OPAQUE(pf[i][j]);    // retire the prefetch before the store burst
         unit_barrier<CC>(ctr, epoch);
-        pack_frame_pairs_any<T, SH, CC, M>(data_off, payload + f * g.payload_stride, TB + 64, g.bits, g.le, utid);
+        pack_frame_pairs_any<T, SH, CC, M>(data_off, payload + f * g.payload_stride, TB + 32, g.bits, g.le, utid);
         unit_barrier<CC>(ctr, epoch);
         if (absmax != nullptr && utid0 == 0) {                // plain store: no atomics, no memset before the launch
-            const u64* wm = reinterpret_cast<const u64*>(smem + TB + 64) + unit * CC;
+            const u64* wm = reinterpret_cast<const u64*>(smem + TB + 32) + unit * CC;
             u64 m = wm[0];
             if constexpr (CC == 2) m = wm[1] > m ? wm[1] : m;
             *FRAD_GPTR(u64, absmax + f) = m;

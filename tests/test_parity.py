@@ -53,7 +53,7 @@ def check_p0_payload(got, want, bits, le, fmt, N):
     scale = max(np.max(np.abs(wv)), 1e-300)
     lg = max(np.log2(N), 1.0)
     if f32:
-        store_eps = {12: 2.0 ** -7, 16: 2.0 ** -10, 24: 2.0 ** -15, 32: 0, 48: 0, 64: 0}[bits]
+        store_eps = {12: 2.0 ** -6, 16: 2.0 ** -10, 24: 2.0 ** -15, 32: 0, 48: 0, 64: 0}[bits]   # one step of the stored mantissa (12 bit: 6 bits, truncated)
         assert np.max(np.abs(gv - wv)) <= 8 * EPS32 * scale * lg + store_eps * scale
         return 0
     if bits >= 48:
