@@ -258,6 +258,7 @@ void frad_plan_clear(void) {
     g_tables.clear(); g_direct.clear();
     blue_clear();
     crc_clear();
+    p1_clear();
 }
 
 int frad_p4_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C, int64_t frame_stride,

@@ -62,6 +62,7 @@ void blue_clear();
 int blue_last_hip_error();
 // CRC-32 tables (frad_crc.hip)
 void crc_clear();
+void p1_clear();         // profile-1 band maps (frad_p1.hip)
 int crc_last_hip_error();
 
 }  // namespace frad

@@ -110,6 +110,14 @@ constexpr size_t kLds = 160 * 1024;
 
 }  // namespace
 
+namespace frad {
+void p1_clear() {                                            // frad_plan_clear: the per-(N, rate) band maps
+    std::lock_guard<std::mutex> lk(g_band_mu);
+    for (auto& kv : g_band) (void)hipFree(kv.second);
+    g_band.clear();
+}
+}  // namespace frad
+
 extern "C" {
 
 int frad_p1_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C, int64_t frame_stride,
