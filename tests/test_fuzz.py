@@ -81,6 +81,8 @@ def test_random_geometries_against_oracle():
         pad = int(rng.choice([0, 0, 0, 16, 5]))
         raw_be = bool(rng.integers(0, 4))                    # False: big-endian ints normalised like little-endian ones
         done[_check(be, rng, profile, N, C, F, fmt, bits, le, offset, hop, pad, raw_be)] += 1
+        if (i + 1) % 5000 == 0:
+            print("fuzz progress:", i + 1, done, flush=True)
     print("fuzz:", rounds, "rounds", done)
     assert done["ok"] >= 0.65 * rounds, done
 
