@@ -11,6 +11,8 @@ import numpy as np
 
 
 class HipBridge:
+    _pinned = None
+
     def __init__(self, device=None):
         import torch
         from . import core
@@ -21,8 +23,24 @@ class HipBridge:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
 
     def _up(self, data: bytes):
-        return self.torch.frombuffer(bytearray(data), dtype=self.torch.uint8).to(self.device) if len(data) else \
-            self.torch.empty(0, dtype=self.torch.uint8, device=self.device)
+        """host bytes -> device uint8 tensor, straight from the caller's (read-only) buffer"""
+        import warnings
+        if not len(data):
+            return self.torch.empty(0, dtype=self.torch.uint8, device=self.device)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                   # torch warns about non-writable memory; it is only read
+            return self.torch.frombuffer(data, dtype=self.torch.uint8).to(self.device)
+
+    def _down_bytes(self, dev) -> bytes:
+        """device uint8 tensor -> bytes through a cached pinned staging buffer (no pageable bounce, no fresh
+        page faults for the intermediate copy)"""
+        t = self.torch
+        n = dev.numel()
+        pin = HipBridge._pinned                               # one staging buffer per process, grown on demand
+        if pin is None or pin.numel() < n:
+            pin = HipBridge._pinned = t.empty(max(n, 1 << 20), dtype=t.uint8, pin_memory=True)
+        pin[:n].copy_(dev.reshape(-1))
+        return pin[:n].numpy().tobytes()
 
     def lossless_encode(self, profile, pcm: bytes, fmt, n_frames, N, C, bits, little_endian, raw_be_ints=True):
         """-> list of (payload bytes, bits actually used) per frame."""
@@ -60,7 +78,20 @@ class HipBridge:
         crc = core.crc32_frames(pay, nb)
         stream[:, :28] = t.frombuffer(bytearray(head_fn(nb)), dtype=t.uint8).to(self.device)
         stream[:, 28:32] = crc.view(t.uint8).view(n_frames, 4).flip(1)       # big-endian, as int.to_bytes(4, "big")
-        return stream.cpu().numpy().tobytes()
+        return self._down_bytes(stream)
+
+    def lossless_decode_strided(self, profile, region, n_frames, stride, nbytes, N, C, bits, little_endian) -> np.ndarray:
+        """Frames that sit equally spaced in the stream (``region`` = first payload byte .. last payload byte, a
+        read-only buffer): one H2D copy of the region, headers and all, and the kernels step over it with
+        ``payload_stride = stride``; no per-frame host copies."""
+        import warnings
+        t = self.torch
+        if nbytes != self.core._lib.load().payload_bytes(N, C, bits):
+            return None                                       # header length and geometry disagree: frame-by-frame path decides
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                   # read-only buffer: it is only copied to the device
+            dev = t.frombuffer(region, dtype=t.uint8).to(self.device)
+        return self.core.digital_batch(profile, dev, n_frames, N, C, bits, little_endian, payload_stride=stride).cpu().numpy()
 
     def lossless_decode(self, profile, payloads: list, N, C, bits, little_endian) -> np.ndarray:
         n = len(payloads)

@@ -62,8 +62,21 @@ class Decoder:
         return self.asfh
 
     # ------------------------------------------------------------------ batched decode of one run of frames
-    def _decode_run(self, key, payloads: list) -> list:
+    def _decode_run(self, key, entries: list) -> list:
+        """entries: (payload bytes or None, offset in self._data, length) per frame of the run"""
         profile, fsize, channels, depth_idx, endian, srate, ratio = key
+        strided = getattr(self.bridge, "lossless_decode_strided", None)
+        if (profile != 1 and strided is not None and len(entries) > 1 and all(e[0] is None for e in entries)):
+            step = entries[1][1] - entries[0][1]
+            if step > 0 and all(entries[i + 1][1] - entries[i][1] == step for i in range(len(entries) - 1)):
+                first, nb = entries[0][1], entries[0][2]
+                region = memoryview(self._data)[first:entries[-1][1] + nb]
+                pcm = strided(profile, region, len(entries), step, nb, fsize, channels, _LOSSLESS_DEPTHS[depth_idx], endian)
+                if pcm is not None:
+                    if self.overlap_fragment.size:
+                        return self._overlap_host(pcm, key)
+                    return list(pcm)
+        payloads = [e[0] if e[0] is not None else self._data[e[1]:e[1] + e[2]] for e in entries]
         if profile == 1:
             bits = _P1_DEPTHS[depth_idx]
             qs = np.zeros((len(payloads), fsize * channels), np.int32)
@@ -150,16 +163,21 @@ class Decoder:
         if len(self._data) - self._pos < need:
             self.broken_frame = stream_was_empty                # process(b'') marks a truncated frame (decoder.py:58-60)
             return None
-        frad = self._data[self._pos:self._pos + need]
+        off = self._pos
         self._pos += need
         a = self.asfh
         if a.profile not in (0, 1, 4):
             raise NotImplementedError(f"profile {a.profile} is not built (upstream: in development)")
-        if a.ecc:
-            frad = _strip_ecc(frad, a.ecc_dsize, a.ecc_codesize)
+        # lossless payloads stay where they are in the stream (offset, length): a run of equally spaced frames goes to
+        # the device as one strided buffer; everything else is cut out here
+        frad = None
+        if a.profile == 1 or a.ecc:
+            frad = self._data[off:off + need]
+            if a.ecc:
+                frad = _strip_ecc(frad, a.ecc_dsize, a.ecc_codesize)
         key = (a.profile, a.fsize, a.channels, a.bit_depth_index, a.endian, a.srate, a.overlap_ratio)
         a.clear()
-        return key, frad
+        return key, (frad, off, need if frad is None else len(frad))
 
     def process(self, stream: bytes) -> DecodeResult:
         """Parse as the reference does (decoder.py:51-108) but decode runs of like frames in one launch each."""
@@ -185,7 +203,7 @@ class Decoder:
                 if got is None:
                     break
                 key, frad = got
-                if key != run_key or (key[0] != 1 and run and len(frad) != len(run[0])):
+                if key != run_key or (key[0] != 1 and run and frad[2] != run[0][2]):
                     close_run()
                     run_key = key
                 run.append(frad)
