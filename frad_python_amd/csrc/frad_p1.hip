@@ -100,6 +100,34 @@ void go_inv(const FastCfg& c, size_t lds, dim3 grid, hipStream_t s, const int32_
     else { allow_lds(k_p1_inv<LOG2M, 1024>, lds); hipLaunchKernelGGL((k_p1_inv<LOG2M, 1024>), grid, dim3(c.threads), lds, s, q, tq, out, tw, post, g, tb); }
 }
 
+// channel-group variants (frames wider than a CU's LDS): cg channels per pass, <= 512 threads
+template <int LOG2M>
+void go_fwd_grp(int lg, int threads, size_t lds, dim3 grid, hipStream_t s, const unsigned char* pcm, int32_t* q, int32_t* tq,
+                const Tables& t, const Geom& g, const P1Tables& tb) {
+    const cx<double>* tw = static_cast<const cx<double>*>(t.tw); const cx<double>* post = static_cast<const cx<double>*>(t.post);
+#define GO(LGV) do { allow_lds(k_p1_fwd_grp<LOG2M, LGV, 512>, lds); \
+        hipLaunchKernelGGL((k_p1_fwd_grp<LOG2M, LGV, 512>), grid, dim3(threads), lds, s, pcm, q, tq, tw, post, g, tb); } while (0)
+    switch (lg) { case 0: GO(0); break; case 1: GO(1); break; case 2: GO(2); break; default: GO(3); break; }
+#undef GO
+}
+template <int LOG2M>
+void go_inv_grp(int threads, size_t lds, dim3 grid, hipStream_t s, const int32_t* q, const int32_t* tq, double* out,
+                const Tables& t, const Geom& g, const P1Tables& tb) {
+    const cx<double>* tw = static_cast<const cx<double>*>(t.tw); const cx<double>* post = static_cast<const cx<double>*>(t.post);
+    allow_lds(k_p1_inv_grp<LOG2M, 512>, lds);
+    hipLaunchKernelGGL((k_p1_inv_grp<LOG2M, 512>), grid, dim3(threads), lds, s, q, tq, out, tw, post, g, tb);
+}
+// group width for profile 1: the FFT buffers plus the quantiser's scratch must fit; 0 = no group geometry
+int p1_group(const FastCfg& c, int N, int C, size_t kLdsBytes_, size_t& lds) {
+    if (!c.ok || c.cg >= C || c.log2m < 8) return 0;
+    const size_t M = (size_t)1 << c.log2m;
+    int cg = c.cg;
+    while (cg > 0 && ((size_t)cg * M * 16 + p1_scratch_bytes(cg, N) > kLdsBytes_ || cg * c.team > 512)) --cg;
+    if (cg < 1) return 0;
+    lds = (size_t)cg * M * 16 + p1_scratch_bytes(cg, N);
+    return cg;
+}
+
 Geom p1_geom(long long n_frames, int N, int C, long long stride, int n_valid, int dtype, uint32_t flags) {
     Geom g{};
     g.n_frames = n_frames; g.frame_stride = stride; g.payload_stride = 0; g.N = N; g.C = C; g.bits = 32; g.le = 0;
@@ -159,6 +187,21 @@ int frad_p1_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
             case 12: go_fwd<12>(lg, c, lds, grid, s, in, q, tq, t, g, tb, ai); break;
             default: go_fwd<13>(lg, c, lds, grid, s, in, q, tq, t, g, tb, ai); break;
         }
+    } else if (size_t glds = 0; int cgw = p1_group(c, N, C, kLds, glds)) {
+        if (n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
+        Tables t; rc = get_tables(c.log2m, false, t);
+        if (rc != FRAD_OK) return rc;
+        g.fpb = 1; g.cg = cgw;
+        dim3 grid((unsigned)n_frames);
+        const int threads = cgw * c.team;
+        switch (c.log2m) {
+            case 8: go_fwd_grp<8>(lg, threads, glds, grid, s, in, q, tq, t, g, tb); break;
+            case 9: go_fwd_grp<9>(lg, threads, glds, grid, s, in, q, tq, t, g, tb); break;
+            case 10: go_fwd_grp<10>(lg, threads, glds, grid, s, in, q, tq, t, g, tb); break;
+            case 11: go_fwd_grp<11>(lg, threads, glds, grid, s, in, q, tq, t, g, tb); break;
+            case 12: go_fwd_grp<12>(lg, threads, glds, grid, s, in, q, tq, t, g, tb); break;
+            default: go_fwd_grp<13>(lg, threads, glds, grid, s, in, q, tq, t, g, tb); break;
+        }
     } else {
         const size_t lds = 2 * (size_t)N * C * 8 + p1_scratch_bytes(C, N);
         if (lds > kLds || n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
@@ -204,6 +247,21 @@ int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32
             case 11: go_inv<11>(c, lds, grid, s, q, tq, pcm_out, t, g, tb); break;
             case 12: go_inv<12>(c, lds, grid, s, q, tq, pcm_out, t, g, tb); break;
             default: go_inv<13>(c, lds, grid, s, q, tq, pcm_out, t, g, tb); break;
+        }
+    } else if (size_t glds = 0; int cgw = p1_group(c, N, C, kLds, glds)) {
+        if (n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
+        Tables t; rc = get_tables(c.log2m, false, t);
+        if (rc != FRAD_OK) return rc;
+        g.fpb = 1; g.cg = cgw;
+        dim3 grid((unsigned)n_frames);
+        const int threads = cgw * c.team;
+        switch (c.log2m) {
+            case 8: go_inv_grp<8>(threads, glds, grid, s, q, tq, pcm_out, t, g, tb); break;
+            case 9: go_inv_grp<9>(threads, glds, grid, s, q, tq, pcm_out, t, g, tb); break;
+            case 10: go_inv_grp<10>(threads, glds, grid, s, q, tq, pcm_out, t, g, tb); break;
+            case 11: go_inv_grp<11>(threads, glds, grid, s, q, tq, pcm_out, t, g, tb); break;
+            case 12: go_inv_grp<12>(threads, glds, grid, s, q, tq, pcm_out, t, g, tb); break;
+            default: go_inv_grp<13>(threads, glds, grid, s, q, tq, pcm_out, t, g, tb); break;
         }
     } else {
         const size_t lds = 2 * (size_t)N * C * 8 + p1_scratch_bytes(C, N);

@@ -95,16 +95,18 @@ __device__ __forceinline__ double p1_spread(const P1Lds& l, int cf, int k) {
     return y + thres[j];
 }
 
-// K7 epilogue: X[k] of `nfl` frames x C channels sit in LDS (xslot<double, SH>); scratch as above for fpb * C slots.
+// K7 epilogue: X[k] of `nfl` frames x `cw` channels sit in LDS (xslot<double, SH>); the channels are c0 .. c0+cw-1 of
+// the frame's C (c0 = 0, cw = C unless the frame is transformed a channel group at a time); scratch as above for `cfs` slots.
 template <int SH>
 __device__ FRAD_NOINLINE void p1_quantise(int smem_off, int scratch_off, int slots, double scale, double loss, int nb_used, const Geom& g,
-                                          long long f0, int nfl, int32_t* __restrict__ q, int32_t* __restrict__ tq) {
+                                          long long f0, int nfl, int32_t* __restrict__ q, int32_t* __restrict__ tq,
+                                          int c0, int cw, int cfs) {
     FRAD_DYN_SMEM(base);
     unsigned char* smem = base + smem_off;
     const int N = g.N, C = g.C, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
-    const P1Lds l = p1_lds(base + scratch_off, g.fpb * C);
+    const P1Lds l = p1_lds(base + scratch_off, cfs);
     // band energies: one (frame, channel, band) task per wave
-    for (int task = wave; task < nfl * C * P1_BANDS; task += nwaves) {
+    for (int task = wave; task < nfl * cw * P1_BANDS; task += nwaves) {
         const int b = task % P1_BANDS, cf = task / P1_BANDS;
         const int a = l.edge[b], e = l.edge[b + 1];
         double acc = 0.0;
@@ -114,7 +116,7 @@ __device__ FRAD_NOINLINE void p1_quantise(int smem_off, int scratch_off, int slo
     }
     __syncthreads();
     // energies -> thresholds, one entry per thread (p1tools.py:18-33)
-    for (int i = threadIdx.x; i < nfl * C * P1_BANDS; i += blockDim.x) {
+    for (int i = threadIdx.x; i < nfl * cw * P1_BANDS; i += blockDim.x) {
         const int b = i % P1_BANDS;
         double t = 0.0;
         if (b < nb_used) {
@@ -124,47 +126,47 @@ __device__ FRAD_NOINLINE void p1_quantise(int smem_off, int scratch_off, int slo
         l.thres[i] = t;
     }
     __syncthreads();
-    p1_ramp_steps(l, nfl * C);
+    p1_ramp_steps(l, nfl * cw);
     // quantised thresholds, band-major / channel-minor
-    for (int i = threadIdx.x; i < nfl * P1_BANDS * C; i += blockDim.x) {
-        const int fl = i / (P1_BANDS * C), r = i - fl * P1_BANDS * C, b = r / C, c = r - b * C;
-        const double t = l.thres[(fl * C + c) * P1_BANDS + b];
+    for (int i = threadIdx.x; i < nfl * P1_BANDS * cw; i += blockDim.x) {
+        const int fl = i / (P1_BANDS * cw), r = i - fl * P1_BANDS * cw, b = r / cw, j = r - b * cw;
+        const double t = l.thres[(fl * cw + j) * P1_BANDS + b];
         const double v = log(t > 1.0 ? t : 1.0) / log(2.718281828459045 / 2);
-        tq[(f0 + fl) * (long long)(P1_BANDS * C) + r] = (int32_t)rint(copysign(pow(fabs(v), 1.0 / 0.75), v));
+        tq[(f0 + fl) * (long long)(P1_BANDS * C) + b * C + c0 + j] = (int32_t)rint(copysign(pow(fabs(v), 1.0 / 0.75), v));
     }
     __syncthreads();
     // per-bin divide + power-law quantiser, bin-major / channel-minor
-    const int NC = N * C;
-    for (int i = threadIdx.x; i < nfl * NC; i += blockDim.x) {
-        const int fl = i / NC, r = i - fl * NC, k = r / C, c = r - k * C, cf = fl * C + c;
+    const int NW = N * cw;
+    for (int i = threadIdx.x; i < nfl * NW; i += blockDim.x) {
+        const int fl = i / NW, r = i - fl * NW, k = r / cw, j = r - k * cw, cf = fl * cw + j;
         const double x = xslot<double, SH>(smem, cf, slots, k);
         const double div = p1_spread(l, cf, k);
         const double m = (div == 0.0) ? 0.0 * x : x / div;                // x / inf keeps the sign of x
-        q[(f0 + fl) * (long long)NC + r] = (int32_t)rint(p1_quant(m * scale));
+        q[(f0 + fl) * (long long)N * C + (long long)k * C + c0 + j] = (int32_t)rint(p1_quant(m * scale));
     }
 }
 
-// K8 prologue: q / tq -> X[k] in LDS.
+// K8 prologue: q / tq -> X[k] in LDS (channels c0 .. c0+cw-1, as above).
 template <int SH>
 __device__ FRAD_NOINLINE void p1_dequantise(int smem_off, int scratch_off, int slots, double scale, const Geom& g,
-                                            long long f0, int nfl, const int32_t* __restrict__ q, const int32_t* __restrict__ tq) {
+                                            long long f0, int nfl, const int32_t* __restrict__ q, const int32_t* __restrict__ tq,
+                                            int c0, int cw, int cfs) {
     FRAD_DYN_SMEM(base);
     unsigned char* smem = base + smem_off;
     const int N = g.N, C = g.C;
-    const P1Lds l = p1_lds(base + scratch_off, g.fpb * C);
-    for (int i = threadIdx.x; i < nfl * P1_BANDS * C; i += blockDim.x) {
-        const int fl = i / (P1_BANDS * C), r = i - fl * P1_BANDS * C, b = r / C, c = r - b * C;
-        const double t = (double)tq[(f0 + fl) * (long long)(P1_BANDS * C) + r];
-        l.thres[(fl * C + c) * P1_BANDS + b] = pow(2.718281828459045 / 2, p1_quant(t));
+    const P1Lds l = p1_lds(base + scratch_off, cfs);
+    for (int i = threadIdx.x; i < nfl * P1_BANDS * cw; i += blockDim.x) {
+        const int fl = i / (P1_BANDS * cw), r = i - fl * P1_BANDS * cw, b = r / cw, j = r - b * cw;
+        const double t = (double)tq[(f0 + fl) * (long long)(P1_BANDS * C) + b * C + c0 + j];
+        l.thres[(fl * cw + j) * P1_BANDS + b] = pow(2.718281828459045 / 2, p1_quant(t));
     }
     __syncthreads();                                         // also orders p1_tables_to_lds (kernel start) before its readers
-    p1_ramp_steps(l, nfl * C);
+    p1_ramp_steps(l, nfl * cw);
     __syncthreads();
-    const int NC = N * C;
-    const double inv_scale = scale;
-    for (int i = threadIdx.x; i < nfl * NC; i += blockDim.x) {
-        const int fl = i / NC, r = i - fl * NC, k = r / C, c = r - k * C, cf = fl * C + c;
-        const double v = p1_dequant((double)q[(f0 + fl) * (long long)NC + r]) / inv_scale;
+    const int NW = N * cw;
+    for (int i = threadIdx.x; i < nfl * NW; i += blockDim.x) {
+        const int fl = i / NW, r = i - fl * NW, k = r / cw, j = r - k * cw, cf = fl * cw + j;
+        const double v = p1_dequant((double)q[(f0 + fl) * (long long)N * C + (long long)k * C + c0 + j]) / scale;
         xslot<double, SH>(smem, cf, slots, k) = v * p1_spread(l, cf, k);
     }
 }
@@ -186,7 +188,7 @@ k_p1_fwd(const unsigned char* __restrict__ pcm, int32_t* __restrict__ q, int32_t
     fft_team<double, LOG2M, false>(buf, t, tw);
     dct_post<double, LOG2M>(buf, t, post);
     __syncthreads();
-    p1_quantise<SH>(0, g.fpb * g.C * SLOTS * 16, SLOTS, tb.scale, tb.loss, tb.nb_used, g, f0, nfl, q, tq);
+    p1_quantise<SH>(0, g.fpb * g.C * SLOTS * 16, SLOTS, tb.scale, tb.loss, tb.nb_used, g, f0, nfl, q, tq, 0, g.C, g.fpb * g.C);
 }
 
 template <int LOG2M, int MAXT>
@@ -201,12 +203,62 @@ k_p1_inv(const int32_t* __restrict__ q, const int32_t* __restrict__ tq, double* 
     const int cf = threadIdx.x / TEAM, t = threadIdx.x - cf * TEAM;
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem) + (long long)cf * SLOTS;
     p1_tables_to_lds(smem + g.fpb * g.C * SLOTS * 16, g.fpb * g.C, tb, g.N);
-    p1_dequantise<SH>(0, g.fpb * g.C * SLOTS * 16, SLOTS, tb.scale, g, f0, nfl, q, tq);
+    p1_dequantise<SH>(0, g.fpb * g.C * SLOTS * 16, SLOTS, tb.scale, g, f0, nfl, q, tq, 0, g.C, g.fpb * g.C);
     __syncthreads();
     dct_pre_inverse<double, LOG2M>(buf, t, post);
     fft_team<double, LOG2M, true>(buf, t, tw);
     __syncthreads();
     store_pcm_f64<SH, true>(0, out, g, f0, nfl, SLOTS);
+}
+
+// Frames whose channels exceed a CU's LDS: one frame per block, g.cg channels per pass (stage / transform / quantise
+// per group; the quantiser works channel by channel, so groups are independent).
+template <int LOG2M, int LG, int MAXT>
+__global__ void __launch_bounds__(MAXT)
+k_p1_fwd_grp(const unsigned char* __restrict__ pcm, int32_t* __restrict__ q, int32_t* __restrict__ tq,
+             const cx<double>* __restrict__ tw, const cx<double>* __restrict__ post, Geom g, P1Tables tb) {
+    constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM, SLOTS = padded_slots(M), SH = Plan<LOG2M>::SH;
+    FRAD_DYN_SMEM(smem);
+    const long long f0 = blockIdx.x;
+    const int cf = threadIdx.x / TEAM, t = threadIdx.x - cf * TEAM, cg = g.cg;
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem) + (long long)cf * SLOTS;
+    const int scratch_off = cg * SLOTS * 16;
+    p1_tables_to_lds(smem + scratch_off, cg, tb, g.N);
+    for (int c0 = 0; c0 < g.C; c0 += cg) {
+        const int cgn = g.C - c0 < cg ? g.C - c0 : cg;
+        stage_in_pcm_group<double, LG, SH>(pcm, 0, g, f0, SLOTS, c0, cgn);
+        __syncthreads();
+        int tt = t; FRAD_OPAQUE(tt);
+        fft_team<double, LOG2M, false>(buf, tt, tw);
+        dct_post<double, LOG2M>(buf, tt, post);
+        __syncthreads();
+        p1_quantise<SH>(0, scratch_off, SLOTS, tb.scale, tb.loss, tb.nb_used, g, f0, 1, q, tq, c0, cgn, cg);
+        __syncthreads();
+    }
+}
+
+template <int LOG2M, int MAXT>
+__global__ void __launch_bounds__(MAXT)
+k_p1_inv_grp(const int32_t* __restrict__ q, const int32_t* __restrict__ tq, double* __restrict__ out,
+             const cx<double>* __restrict__ tw, const cx<double>* __restrict__ post, Geom g, P1Tables tb) {
+    constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM, SLOTS = padded_slots(M), SH = Plan<LOG2M>::SH;
+    FRAD_DYN_SMEM(smem);
+    const long long f0 = blockIdx.x;
+    const int cf = threadIdx.x / TEAM, t = threadIdx.x - cf * TEAM, cg = g.cg;
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem) + (long long)cf * SLOTS;
+    const int scratch_off = cg * SLOTS * 16;
+    p1_tables_to_lds(smem + scratch_off, cg, tb, g.N);
+    for (int c0 = 0; c0 < g.C; c0 += cg) {
+        const int cgn = g.C - c0 < cg ? g.C - c0 : cg;
+        p1_dequantise<SH>(0, scratch_off, SLOTS, tb.scale, g, f0, 1, q, tq, c0, cgn, cg);
+        __syncthreads();
+        int tt = t; FRAD_OPAQUE(tt);
+        dct_pre_inverse<double, LOG2M>(buf, tt, post);
+        fft_team<double, LOG2M, true>(buf, tt, tw);
+        __syncthreads();
+        store_pcm_group<SH>(0, out, g, f0, SLOTS, c0, cgn);
+        __syncthreads();
+    }
 }
 
 // any legal compact frame size (160/192/224 * 2^n ...): direct cosine sums, one frame per block
@@ -233,7 +285,7 @@ __global__ void __launch_bounds__(256) k_p1_fwd_direct(const unsigned char* __re
         X[(long long)c * N + k] = acc * inv_n;
     }
     __syncthreads();
-    p1_quantise<-1>(N * C * 8, 2 * N * C * 8, N, tb.scale, tb.loss, tb.nb_used, g, f0, 1, q, tq);
+    p1_quantise<-1>(N * C * 8, 2 * N * C * 8, N, tb.scale, tb.loss, tb.nb_used, g, f0, 1, q, tq, 0, C, C);
 }
 
 template <int UNUSED>
@@ -245,7 +297,7 @@ __global__ void __launch_bounds__(256) k_p1_inv_direct(const int32_t* __restrict
     double* X = reinterpret_cast<double*>(smem);
     double* x = X + (long long)N * C;
     p1_tables_to_lds(smem + 2 * N * C * 8, C, tb, N);
-    p1_dequantise<-1>(0, 2 * N * C * 8, N, tb.scale, g, f0, 1, q, tq);
+    p1_dequantise<-1>(0, 2 * N * C * 8, N, tb.scale, g, f0, 1, q, tq, 0, C, C);
     __syncthreads();
     const unsigned fourN = 4u * (unsigned)N;
     for (int i = threadIdx.x; i < N * C; i += blockDim.x) {

@@ -48,7 +48,8 @@ def test_p1_golden_g4_quantiser_and_decode(be, g4):
 
 
 @pytest.mark.parametrize("geom", [(2048, 2, 48000, 5), (512, 1, 44100, 3), (2048, 1, 96000, 2), (1024, 2, 8000, 2),
-                                  (640, 1, 32000, 2), (128, 2, 48000, 4), (4096, 2, 48000, 1), (2560, 2, 48000, 1)])
+                                  (640, 1, 32000, 2), (128, 2, 48000, 4), (4096, 2, 48000, 1), (2560, 2, 48000, 1),
+                                  (2048, 12, 44100, 1), (4096, 6, 48000, 2), (8192, 3, 96000, 1)])   # the last three: channel groups
 def test_p1_vs_oracle_sizes_and_rates(be, geom):
     N, C, srate, F = geom
     if be.name == "emu" and N > 2048:
