@@ -38,9 +38,15 @@ __device__ __forceinline__ uint32_t f32_to_f16_bits(float f) {
 __device__ __forceinline__ uint32_t f64_to_f16_bits(double d) {
     // round-to-odd into f32 (24 significant bits >= 11 + 2), then the hardware RNE f32 -> f16:
     // the pair is a single correctly rounded f64 -> f16 conversion.
-    float r = __double2float_rz(d);
-    if ((double)r != d) r = u2f(f2u(r) | 1u);
-    return f32_to_f16_bits(r);
+    // Round-to-odd = truncate + sticky bit; built from the one-instruction RNE conversion (step back towards zero when
+    // it rounded away) instead of a round-towards-zero conversion, which costs ~20 instructions on gfx950.
+    const float n = (float)d;
+    uint32_t b = f2u(n);
+    if ((double)n != d) {                                    // inexact (or NaN: the payload bit is set, as before)
+        if (fabs((double)n) > fabs(d)) b -= 1u;               // sign-magnitude: one step towards zero (also from +-inf)
+        b |= 1u;
+    }
+    return f32_to_f16_bits(u2f(b));
 }
 __device__ __forceinline__ float f16_bits_to_f32(uint32_t h) {
     return __half2float(__ushort_as_half((unsigned short)h));
