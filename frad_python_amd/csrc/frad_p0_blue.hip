@@ -57,13 +57,28 @@ __global__ void __launch_bounds__(1024) k_p0_fwd_blue(const unsigned char* __res
     const bool whole = g.in_mode != 0;                       // X area holds all C channels: one whole-frame pack at the end
     for (int c0 = 0; c0 < C; c0 += cg) {
         const int cgn = C - c0 < cg ? C - c0 : cg;
-        for (int q = threadIdx.x; q < N * cgn; q += blockDim.x) {           // a[slot] = v[slot] conj(w_slot)
-            const int n = q / cgn, j = q - n * cgn;
-            const long long e = (long long)n * C + c0 + j;
-            const double v = n < g.n_valid ? cvt_pcm<double>(load_raw(src + (e << LG), LG), g.dtype, g.raw_be) : 0.0;
-            const int slot = makhoul(n, N);
-            const cx<double> w = wconj[slot];
-            bufs[(long long)j * L + phys<double, SH>(slot)] = cx<double>{v * w.x, v * w.y};
+        {                                                                    // a[slot] = v[slot] conj(w_slot)
+            const int total = N * cgn, TH = blockDim.x;
+            auto place = [&](int q, u64 raw) {
+                const int n = q / cgn, j = q - n * cgn;
+                const double v = n < g.n_valid ? cvt_pcm<double>(raw, g.dtype, g.raw_be) : 0.0;
+                const int slot = makhoul(n, N);
+                const cx<double> w = wconj[slot];
+                bufs[(long long)j * L + phys<double, SH>(slot)] = cx<double>{v * w.x, v * w.y};
+            };
+            auto fetch = [&](int q) -> u64 {
+                const int n = q / cgn, j = q - n * cgn;
+                return n < g.n_valid ? load_raw(src + (((long long)n * C + c0 + j) << LG), LG) : 0;
+            };
+            int q = threadIdx.x;
+            for (; q + 7 * TH < total; q += 8 * TH) {                         // eight element loads in flight per lane
+                u64 raw[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) raw[i] = fetch(q + i * TH);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) place(q + i * TH, raw[i]);
+            }
+            for (; q < total; q += TH) place(q, fetch(q));
         }
         for (int q = threadIdx.x; q < (L - N) * cg; q += blockDim.x) {        // zero padding up to L
             const int s = q / cg, j = q - s * cg;
