@@ -471,43 +471,70 @@ __device__ FRAD_NOINLINE void stage_in_quads(const unsigned char* __restrict__ p
         }
     } else if (g.in_mode == 2) {                         // row = 8 bytes: C = 8 >> LG, a quad = 32 contiguous bytes
         constexpr int CC = 8 >> LG;
-        const int quads = g.N / 4;
-        for (int q = threadIdx.x; q < nfl * quads; q += blockDim.x) {
-            const int fl = q / quads, zq = q - fl * quads;
-            const unsigned char* src = pcm + (((f0 + fl) * g.frame_stride * CC) << LG);
-            uint32_t w[8];
-            load_words<8>(src + (long long)zq * 32, w);
+        const int quads = g.N / 4, total = nfl * quads, TH = blockDim.x;
+        dispatch_pcm<LG>(g.dtype, g.raw_be, [&](auto code_tag, auto raw_tag) {       // format resolved once; two quads in flight
+            constexpr int CODE = decltype(code_tag)::value;
+            constexpr bool RAW = decltype(raw_tag)::value != 0;
+            auto fetch = [&](int q, uint32_t (&w)[8]) {
+                const int fl = q / quads, zq = q - fl * quads;
+                load_words<8>(pcm + (((f0 + fl) * g.frame_stride * CC) << LG) + (long long)zq * 32, w);
+            };
+            auto place = [&](int q, const uint32_t (&w)[8]) {
+                const int fl = q / quads, zq = q - fl * quads;
 #pragma unroll
-            for (int c = 0; c < CC; ++c) {
-                cx<T>* buf = reinterpret_cast<cx<T>*>(smem) + (long long)(fl * CC + c) * slots;
-                T e[4];
+                for (int c = 0; c < CC; ++c) {
+                    cx<T>* buf = reinterpret_cast<cx<T>*>(smem) + (long long)(fl * CC + c) * slots;
+                    T e[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) e[i] = cvt_pcm<T>(word_elem<LG>(w, i * CC + c), g.dtype, g.raw_be);
-                buf[phys<T, SH>(zq)] = cx<T>{e[0], e[2]};
-                buf[phys<T, SH>(M - 1 - zq)] = cx<T>{e[3], e[1]};
+                    for (int i = 0; i < 4; ++i) e[i] = cvt_pcm_c<T, CODE, RAW>(word_elem<LG>(w, i * CC + c));
+                    buf[phys<T, SH>(zq)] = cx<T>{e[0], e[2]};
+                    buf[phys<T, SH>(M - 1 - zq)] = cx<T>{e[3], e[1]};
+                }
+            };
+            int q = threadIdx.x;
+            for (; q + TH < total; q += 2 * TH) {
+                uint32_t w0[8], w1[8];
+                fetch(q, w0); fetch(q + TH, w1);
+                place(q, w0); place(q + TH, w1);
             }
-        }
+            for (; q < total; q += TH) { uint32_t w[8]; fetch(q, w); place(q, w); }
+        });
     } else {                                             // row a multiple of 16 bytes: (quad, 16-byte column slab)
         constexpr int EPC = 16 >> LG;
         const int slabs = (C << LG) / 16, quads = g.N / 4;
         const long long rowb = (long long)C << LG;
-        for (int q = threadIdx.x; q < nfl * quads * slabs; q += blockDim.x) {
-            const int fl = q / (quads * slabs), r = q - fl * quads * slabs;
-            const int zq = r / slabs, sl = r - zq * slabs;
-            const unsigned char* src = pcm + (((f0 + fl) * g.frame_stride * C) << LG) + (long long)zq * 4 * rowb + sl * 16;
-            uint32_t w[4][4];
+        const int total = nfl * quads * slabs, TH = blockDim.x;
+        dispatch_pcm<LG>(g.dtype, g.raw_be, [&](auto code_tag, auto raw_tag) {       // format resolved once; two tasks (8 loads) in flight
+            constexpr int CODE = decltype(code_tag)::value;
+            constexpr bool RAW = decltype(raw_tag)::value != 0;
+            auto fetch = [&](int q, uint32_t (&w)[4][4]) {
+                const int fl = q / (quads * slabs), r = q - fl * quads * slabs;
+                const int zq = r / slabs, sl = r - zq * slabs;
+                const unsigned char* src = pcm + (((f0 + fl) * g.frame_stride * C) << LG) + (long long)zq * 4 * rowb + sl * 16;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) load_words<4>(src + i * rowb, w[i]);
+                for (int i = 0; i < 4; ++i) load_words<4>(src + i * rowb, w[i]);
+            };
+            auto place = [&](int q, const uint32_t (&w)[4][4]) {
+                const int fl = q / (quads * slabs), r = q - fl * quads * slabs;
+                const int zq = r / slabs, sl = r - zq * slabs;
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                cx<T>* buf = reinterpret_cast<cx<T>*>(smem) + (long long)(fl * C + sl * EPC + e) * slots;
-                T v[4];
+                for (int e = 0; e < EPC; ++e) {
+                    cx<T>* buf = reinterpret_cast<cx<T>*>(smem) + (long long)(fl * C + sl * EPC + e) * slots;
+                    T v[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = cvt_pcm<T>(word_elem<LG>(w[i], e), g.dtype, g.raw_be);
-                buf[phys<T, SH>(zq)] = cx<T>{v[0], v[2]};
-                buf[phys<T, SH>(M - 1 - zq)] = cx<T>{v[3], v[1]};
+                    for (int i = 0; i < 4; ++i) v[i] = cvt_pcm_c<T, CODE, RAW>(word_elem<LG>(w[i], e));
+                    buf[phys<T, SH>(zq)] = cx<T>{v[0], v[2]};
+                    buf[phys<T, SH>(M - 1 - zq)] = cx<T>{v[3], v[1]};
+                }
+            };
+            int q = threadIdx.x;
+            for (; q + TH < total; q += 2 * TH) {
+                uint32_t w0[4][4], w1[4][4];
+                fetch(q, w0); fetch(q + TH, w1);
+                place(q, w0); place(q + TH, w1);
             }
-        }
+            for (; q < total; q += TH) { uint32_t w[4][4]; fetch(q, w); place(q, w); }
+        });
     }
 }
 
