@@ -846,20 +846,24 @@ __device__ FRAD_NOINLINE void stage_in_pcm_group(const unsigned char* __restrict
     const unsigned char* src = pcm + ((f * g.frame_stride * C) << LG);
     const int total = N * cgn, TH = blockDim.x;
     int q0 = threadIdx.x;
-    if (g.n_valid == N) {                                    // batches of 8 element loads in flight per lane
-        for (; q0 + 7 * TH < total; q0 += 8 * TH) {
-            u64 raw[8];
+    if (g.n_valid == N) {                                    // batches of 8 element loads in flight per lane, format resolved once
+        dispatch_pcm<LG>(g.dtype, g.raw_be, [&](auto code_tag, auto raw_tag) {
+            constexpr int CODE = decltype(code_tag)::value;
+            constexpr bool RAW = decltype(raw_tag)::value != 0;
+            for (; q0 + 7 * TH < total; q0 += 8 * TH) {
+                u64 raw[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int q = q0 + i * TH, n = q / cgn, j = q - n * cgn;
-                raw[i] = load_raw(src + (((long long)n * C + c0 + j) << LG), LG);
-            }
+                for (int i = 0; i < 8; ++i) {
+                    const int q = q0 + i * TH, n = q / cgn, j = q - n * cgn;
+                    raw[i] = load_raw(src + (((long long)n * C + c0 + j) << LG), LG);
+                }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int q = q0 + i * TH, n = q / cgn, j = q - n * cgn;
-                xslot<T, SH>(smem, j, slots, makhoul(n, N)) = cvt_pcm<T>(raw[i], g.dtype, g.raw_be);
+                for (int i = 0; i < 8; ++i) {
+                    const int q = q0 + i * TH, n = q / cgn, j = q - n * cgn;
+                    xslot<T, SH>(smem, j, slots, makhoul(n, N)) = cvt_pcm_c<T, CODE, RAW>(raw[i]);
+                }
             }
-        }
+        });
     }
     for (int q = q0; q < total; q += TH) {
         const int n = q / cgn, j = q - n * cgn;
