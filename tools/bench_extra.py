@@ -77,6 +77,13 @@ out.append(line("cfg5 p1 quantise (K7)", F * (N * C * 2 + N * C * 4 + 27 * C * 4
 out.append(line("cfg5 p1 dequantise+IDCT (K8)", F * (N * C * 4 + 27 * C * 4 + N * C * 8), timeit(lambda: core.p1_digital_batch(q, tq, N, C, 16, 48000)), F * hop * C))
 dec = core.p1_digital_batch(q, tq, N, C, 16, 48000)
 out.append(line("cfg5 overlap-add", F * (N * C * 8 + hop * C * 8), timeit(lambda: core.p1_overlap_add(dec, 16)), F * hop * C))
+# device-copy microbench (what a plain copy reaches of the nominal 8 TB/s on this box): read + write bytes / time
+for mib in (256, 1024):
+    a = torch.empty(mib << 20, dtype=torch.uint8, device=dev); b = torch.empty_like(a)
+    ms = timeit(lambda: b.copy_(a))
+    out.append({"case": f"device copy {mib} MiB (read + write)", "ms": round(ms, 4), "GB/s": round(2 * (mib << 20) / ms / 1e6, 1),
+                "hbm_frac": round(2 * (mib << 20) / ms / 1e6 / 8000, 4)})
+    del a, b
 # end to end through the streaming API (SURVEY 8d "separate line"): host bytes in -> FrAD stream bytes out and
 # back, i.e. H2D + kernels + D2H + the Python ASFH framer / CRC, one process() call per 60 s of audio
 import time  # noqa: E402
