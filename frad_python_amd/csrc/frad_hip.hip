@@ -259,6 +259,7 @@ void frad_plan_clear(void) {
     blue_clear();
     crc_clear();
     p1_clear();
+    wave_clear();
 }
 
 int frad_p4_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C, int64_t frame_stride,
@@ -363,6 +364,7 @@ int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
     const int ao = (aligned16(payload) && payload_stride % 16 == 0) ? 1 : 0;
     const unsigned char* in = static_cast<const unsigned char*>(pcm);
     unsigned char* out = static_cast<unsigned char*>(payload);
+    if (launch_p0_fwd_wave(lg, s, in, out, absmax, g, ai, ao, unit_neg)) { HIPCHK(hipGetLastError()); return FRAD_OK; }
     const FastCfg c = fast_cfg(N, C, f32);
     if (c.ok) {
         Tables tb; rc = get_tables(c.log2m, f32, tb);

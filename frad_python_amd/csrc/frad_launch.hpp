@@ -60,6 +60,12 @@ int launch_p0_inv_blue(hipStream_t s, const unsigned char* pay, double* out, Geo
 int blue_prepare(int N);
 void blue_clear();
 int blue_last_hip_error();
+// wave-autonomous kernels for N = 2048, C <= 2, 16/32/64-bit storage (frad_p0_wave.hip): 1 = launched, 0 = not applicable
+typedef void (*unit_root_fn)(long long, long long, long double&, long double&);      // exp(-i pi p / q)
+int launch_p0_fwd_wave(int lg, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* absmax, const Geom& g,
+                       int aligned_in, int aligned_out, unit_root_fn unit);
+void wave_blob_build(std::vector<unsigned char>& bytes, unit_root_fn unit);
+void wave_clear();
 // CRC-32 tables (frad_crc.hip)
 void crc_clear();
 void p1_clear();         // profile-1 band maps (frad_p1.hip)

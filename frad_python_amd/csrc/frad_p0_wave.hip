@@ -1,0 +1,115 @@
+// wave-autonomous profile-0 kernels (frad_wave.hpp): table blob, instantiation and launch policy
+#include "frad_wave.hpp"
+#include "frad_launch.hpp"
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace frad {
+namespace {
+
+int wave_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+// experiments only (tuning knobs): read once per process
+bool wave_disabled() { static const bool d = [] { const char* e = getenv("FRAD_TUNE_NO_WAVE"); return e && e[0] == '1'; }(); return d; }
+
+std::mutex g_wave_mu;
+std::map<int, void*> g_wave_blob;                    // device -> LDS image of WaveLayout
+int g_wave_hip = 0;
+
+template <int LG, int CC, int BITS>
+void go_fwd_wave(const void* blob, int grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* am, const Geom& g) {
+    allow_lds(k_p0_fwd_wave<LG, CC, BITS>, kWaveLdsBytes);
+    hipLaunchKernelGGL((k_p0_fwd_wave<LG, CC, BITS>), dim3(grid), dim3(256), kWaveLdsBytes, s, pcm, pay, am,
+                       static_cast<const cx<double>*>(blob), g);
+}
+template <int LG, int CC>
+void go_fwd_wave_bits(const void* blob, int grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* am, const Geom& g) {
+    switch (g.bits) {
+        case 16: go_fwd_wave<LG, CC, 16>(blob, grid, s, pcm, pay, am, g); break;
+        case 32: go_fwd_wave<LG, CC, 32>(blob, grid, s, pcm, pay, am, g); break;
+        default: go_fwd_wave<LG, CC, 64>(blob, grid, s, pcm, pay, am, g); break;
+    }
+}
+template <int CC>
+void go_fwd_wave_lg(int lg, const void* blob, int grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* am, const Geom& g) {
+    switch (lg) {
+        case 0: go_fwd_wave_bits<0, CC>(blob, grid, s, pcm, pay, am, g); break;
+        case 1: go_fwd_wave_bits<1, CC>(blob, grid, s, pcm, pay, am, g); break;
+        case 2: go_fwd_wave_bits<2, CC>(blob, grid, s, pcm, pay, am, g); break;
+        default: go_fwd_wave_bits<3, CC>(blob, grid, s, pcm, pay, am, g); break;
+    }
+}
+
+}  // namespace
+
+// Host image of WaveLayout.  `unit(p, q, re, im)` returns exp(-i pi p / q) (long double, exact octant symmetry).
+void wave_blob_build(std::vector<unsigned char>& bytes, void (*unit)(long long, long long, long double&, long double&)) {
+    constexpr int N = 2048;
+    std::vector<cx<double>> out(WaveLayout::SLOTS);
+    for (int k2 = 0; k2 < 32; ++k2)
+        for (int l = 0; l < 32; ++l) {
+            long double re, im; unit(2LL * l * k2, 1024, re, im);                 // W_1024^(l k2)
+            out[WaveLayout::TW1 + k2 * 32 + l] = cx<double>{(double)re, (double)im};
+        }
+    auto wk = [&](int k) { long double re, im; unit(k, 2LL * N, re, im); return cx<double>{(double)re, (double)im}; };
+    auto gk = [&](int k) { long double re, im; unit((long long)N + 5LL * k, 2LL * N, re, im); return cx<double>{(double)re, (double)im}; };
+    out[WaveLayout::TW1 + 0] = wk(512);                                         // row 0 of TW1 is all ones and never read as such
+    out[WaveLayout::TW1 + 1] = gk(512);
+    for (int u = 0; u < 16; ++u)
+        for (int a = 0; a < 32; ++a) {
+            const int k = wave_job_k(a, u);
+            out[WaveLayout::PW + u * 32 + a] = wk(k);
+            out[WaveLayout::PG + u * 32 + a] = gk(k);
+        }
+    bytes.assign((unsigned char*)out.data(), (unsigned char*)(out.data() + out.size()));
+}
+
+static const void* wave_blob(void (*unit)(long long, long long, long double&, long double&)) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_wave_mu);
+    auto it = g_wave_blob.find(dev);
+    if (it != g_wave_blob.end()) return it->second;
+    std::vector<unsigned char> bytes;
+    wave_blob_build(bytes, unit);
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, bytes.size());
+    if (e == hipSuccess) e = hipMemcpy(d, bytes.data(), bytes.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { g_wave_hip = (int)e; return nullptr; }
+    g_wave_blob[dev] = d;
+    return d;
+}
+void wave_clear() {
+    std::lock_guard<std::mutex> lk(g_wave_mu);
+    for (auto& kv : g_wave_blob) (void)hipFree(kv.second);
+    g_wave_blob.clear();
+}
+
+bool wave_geometry(int N, int C, int bits) { return N == 2048 && (C == 1 || C == 2) && (bits == 16 || bits == 32 || bits == 64); }
+
+// 1 = launched, 0 = not this kernel's geometry (caller falls back to the unit / one-shot kernels)
+int launch_p0_fwd_wave(int lg, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* am, const Geom& g, int ai, int ao,
+                       void (*unit)(long long, long long, long double&, long double&)) {
+    if (wave_disabled() || !wave_geometry(g.N, g.C, g.bits) || !ai || !ao || g.n_valid != g.N) return 0;
+    if ((g.dtype >> 3) == 2 && ((g.dtype >> 1) & 3) <= 2) return 0;   // f16 / f32 PCM: float32 compute stays with the f32 kernels
+    const void* blob = wave_blob(unit);
+    if (blob == nullptr) return 0;
+    const long long units = g.C == 2 ? g.n_frames : (g.n_frames + 1) / 2;
+    const long long nb = (units + 3) / 4, cap = wave_cu_count();
+    const int grid = (int)(nb < cap ? nb : cap);
+    if (g.C == 2) go_fwd_wave_lg<2>(lg, blob, grid, s, pcm, pay, am, g);
+    else go_fwd_wave_lg<1>(lg, blob, grid, s, pcm, pay, am, g);
+    return 1;
+}
+
+}  // namespace frad
