@@ -29,7 +29,7 @@ int g_wave_hip = 0;
 template <int LG, int CC, int BITS>
 void go_fwd_wave(const void* blob, int grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* am, const Geom& g) {
     allow_lds(k_p0_fwd_wave<LG, CC, BITS>, kWaveLdsBytes);
-    hipLaunchKernelGGL((k_p0_fwd_wave<LG, CC, BITS>), dim3(grid), dim3(256), kWaveLdsBytes, s, pcm, pay, am,
+    hipLaunchKernelGGL((k_p0_fwd_wave<LG, CC, BITS>), dim3(grid), dim3(64 * kWaveWaves), kWaveLdsBytes, s, pcm, pay, am,
                        static_cast<const cx<double>*>(blob), g);
 }
 template <int LG, int CC>
@@ -42,12 +42,16 @@ void go_fwd_wave_bits(const void* blob, int grid, hipStream_t s, const unsigned 
 }
 template <int CC>
 void go_fwd_wave_lg(int lg, const void* blob, int grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* am, const Geom& g) {
+#ifdef FRAD_WAVE_EXPERIMENT                                    // diagnostic builds: the headline element size only
+    go_fwd_wave_bits<1, CC>(blob, grid, s, pcm, pay, am, g); (void)lg;
+#else
     switch (lg) {
         case 0: go_fwd_wave_bits<0, CC>(blob, grid, s, pcm, pay, am, g); break;
         case 1: go_fwd_wave_bits<1, CC>(blob, grid, s, pcm, pay, am, g); break;
         case 2: go_fwd_wave_bits<2, CC>(blob, grid, s, pcm, pay, am, g); break;
         default: go_fwd_wave_bits<3, CC>(blob, grid, s, pcm, pay, am, g); break;
     }
+#endif
 }
 
 }  // namespace
@@ -95,6 +99,15 @@ void wave_clear() {
     g_wave_blob.clear();
 }
 
+#if defined(FRAD_WAVE_STAMPS)
+extern "C" int frad_debug_wave_stamps(unsigned long long* out, int reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_stamps), sizeof(z)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_wave_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
 bool wave_geometry(int N, int C, int bits) { return N == 2048 && (C == 1 || C == 2) && (bits == 16 || bits == 32 || bits == 64); }
 
 // 1 = launched, 0 = not this kernel's geometry (caller falls back to the unit / one-shot kernels)
@@ -105,10 +118,12 @@ int launch_p0_fwd_wave(int lg, hipStream_t s, const unsigned char* pcm, unsigned
     const void* blob = wave_blob(unit);
     if (blob == nullptr) return 0;
     const long long units = g.C == 2 ? g.n_frames : (g.n_frames + 1) / 2;
-    const long long nb = (units + 3) / 4, cap = wave_cu_count();
+    const long long nb = (units + kWaveWaves - 1) / kWaveWaves, cap = wave_cu_count();
     const int grid = (int)(nb < cap ? nb : cap);
-    if (g.C == 2) go_fwd_wave_lg<2>(lg, blob, grid, s, pcm, pay, am, g);
-    else go_fwd_wave_lg<1>(lg, blob, grid, s, pcm, pay, am, g);
+    Geom gg = g;
+    { static const int st = [] { const char* e = getenv("FRAD_TUNE_WAVE_STAGGER"); return e ? atoi(e) : 5; }(); gg.cg = st; }   // s_sleep units of the start stagger
+    if (g.C == 2) go_fwd_wave_lg<2>(lg, blob, grid, s, pcm, pay, am, gg);
+    else go_fwd_wave_lg<1>(lg, blob, grid, s, pcm, pay, am, gg);
     return 1;
 }
 

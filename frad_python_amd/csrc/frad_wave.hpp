@@ -12,7 +12,8 @@
 //
 //   stage raw PCM bytes in LDS (16-byte copies, no conversion)      -> each lane picks its Makhoul pairs
 //   pass 1: 32-point DFT in registers over z[l + 32 j], twiddle W_1024^(l k2)
-//   ONE exchange through LDS (XOR-swizzled, conflict-free both ways)
+//   ONE exchange through LDS (XOR-swizzled, conflict-free both ways), real plane then imaginary plane, so that a
+//   wave needs 16 KiB instead of 32 and eight waves (two per SIMD) share a CU
 //   pass 2: lane a needs Z[a + 32 m] AND its DCT partners Z[M - k], which live in residue -a.  It therefore
 //           computes the even-m half of residue a and the odd-m half of residue -a (a 32-point DFT splits into
 //           two 16-point DFTs of the sums and the twiddled differences: half the outputs for half the work), so
@@ -21,22 +22,26 @@
 //   pack: storage codes go to LDS at their payload position, come back as 16-byte rows, coalesced stores.
 //
 // No s_barrier, no inter-wave traffic: the LDS serves one wave's instructions in order, so phases only need the
-// compiler kept honest (team_sync<64>).  One wave per SIMD (4 x 32 KiB + 32 KiB of tables = 160 KiB), up to 512
-// VGPRs each; the next frame's PCM is prefetched into registers during the transform.
+// compiler kept honest (team_sync<64>).  Two waves per SIMD (8 x 16 KiB + 32 KiB of tables = 160 KiB), 256 VGPRs
+// each; the next frame's PCM is prefetched into registers during the transform.
 #pragma once
 #include "frad_kernels.hpp"
+#include <type_traits>
 
 namespace frad {
 
-// LDS table blob (complex<double> slots), shared by the four waves of a block:
+// LDS table blob (complex<double> slots), shared by the eight waves of a block:
 //   TW1[k2 * 32 + l] = W_1024^(l * k2)                (row 0 is never used as a twiddle: slots 0, 1 hold w_512, g_512)
 //   PW [u * 32 + a]  = w_k, PG[u * 32 + a] = g_k     for the pair job of (lane a, slot u), k = wave_job_k(a, u)
+// The kernels scale w_k, g_k by the exact power of two 1/2N (x the deferred PCM normalisation) while copying them in.
 struct WaveLayout { static constexpr int TW1 = 0, PW = 1024, PG = 1536, SLOTS = 2048; };
 constexpr int kWaveTableBytes = WaveLayout::SLOTS * 16;
-constexpr int kWaveBufBytes = 32768;
-constexpr int kWaveLdsBytes = kWaveTableBytes + 4 * kWaveBufBytes;     // = 160 KiB
+constexpr int kWavePlaneSlots = 34 * 32;                 // one padded exchange plane: 32 rows of 32 doubles + 2 (see pslot)
+constexpr int kWaveBufBytes = 2 * kWavePlaneSlots * 8;   // 17 408 B: two planes (one per channel); the raw bytes and the payload staging alias them
+constexpr int kWaveWaves = 7;                            // 7 x 17 KiB + 32 KiB of tables = 151 of the 160 KiB
+constexpr int kWaveLdsBytes = kWaveTableBytes + kWaveWaves * kWaveBufBytes + 16;   // + the block's work counter
 
-// pair job (lane a in [0, 32), slot u in [0, 16)) -> its k in [0, M/2]; see frad_wave.hpp header and pass 2 below
+// pair job (lane a in [0, 32), slot u in [0, 16)) -> its k in [0, M/2]; see the header comment and pass 2 below
 __host__ __device__ constexpr int wave_job_k(int a, int u) {
     return u < 8 ? a + 64 * u : (a == 0 ? 992 - 64 * u : 1024 - a - 64 * u);
 }
@@ -65,11 +70,11 @@ template <int E, bool INV, typename T> __device__ __forceinline__ cx<T> mul_w32(
 // decimation in frequency, first stage of a 32-point DFT: e[n] = lo[n] + hi[n], o[n] = (lo[n] - hi[n]) W_32^n; the
 // 16-point DFTs of e and o are the even and the odd outputs
 template <bool INV, typename T, int I = 0>
-__device__ __forceinline__ void dif32_stage(const cx<T> (&lo)[16], const cx<T> (&hi)[16], cx<T> (&e)[16], cx<T> (&o)[16]) {
+__device__ __forceinline__ void dif32_stage(const cx<T> (&z)[32], cx<T> (&e)[16], cx<T> (&o)[16]) {
     if constexpr (I < 16) {
-        e[I] = lo[I] + hi[I];
-        o[I] = mul_w32<I, INV>(lo[I] - hi[I]);
-        dif32_stage<INV, T, I + 1>(lo, hi, e, o);
+        e[I] = z[I] + z[I + 16];
+        o[I] = mul_w32<I, INV>(z[I] - z[I + 16]);
+        dif32_stage<INV, T, I + 1>(z, e, o);
     }
 }
 template <bool INV, typename T, int I = 0>
@@ -77,13 +82,45 @@ __device__ __forceinline__ void tw32_apply(cx<T> (&o)[16]) {          // o[n] *=
     if constexpr (I < 16) { o[I] = mul_w32<I, INV>(o[I]); tw32_apply<INV, T, I + 1>(o); }
 }
 
-// XOR-swizzled exchange slot of (row r, column c), r and c in [0, 32): 32 r + (c ^ (r & 15)).  Writers hold c = lane
-// and sweep r (8 consecutive lanes -> 8 distinct 16-byte columns), readers hold r = lane and sweep c (16 lanes of a
-// ds_read_b128 group -> 16 distinct columns): no bank conflicts either way.
-__device__ __forceinline__ int xslot(int r, int c) { return 32 * r + (c ^ (r & 15)); }
+// Exchange plane of 32 x 32 doubles, rows padded to 34: (row r, column c) lives at 34 r + 2 (c & 15) + (c >> 4), i.e.
+// columns c and c + 16 are neighbours.  Writers hold c = lane and sweep r (ds_write_b64: 16 consecutive lanes cover 64
+// banks), readers hold r = lane and fetch the pair (c, c + 16) -- exactly what the first stage of pass 2 adds and
+// subtracts -- with one ds_read_b128 (row pitch 272 B = 4 banks mod 64: 16 lanes cover 64 banks).  No conflicts
+// either way, and -- unlike an XOR swizzle -- the swept index stays in the instruction's immediate offset: three
+// address registers per wave instead of ~100.
+__device__ __forceinline__ int pslot(int r, int c) { return 34 * r + 2 * (c & 15) + (c >> 4); }
+
+// Diagnostic build only (-DFRAD_WAVE_STAMPS): per-phase shader-clock totals of wave 0 of every block, summed into
+// g_wave_stamps[phase] (cycles) and g_wave_stamps[8] (units); no stamp executes in the product build.
+#if defined(FRAD_WAVE_STAMPS) && !defined(FRAD_HOST_EMULATION)
+__device__ unsigned long long g_wave_stamps[16];
+#define FRAD_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
+#define FRAD_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime(), st_units = 0
+#define FRAD_STAMP_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_wave_stamps[i_], st_acc[i_]); atomicAdd(&g_wave_stamps[8], st_units); } } while (0)
+#else
+#define FRAD_STAMP(i) ((void)0)
+#define FRAD_STAMP_DECL ((void)0)
+#define FRAD_STAMP_FLUSH ((void)0)
+#endif
+
+// work distribution inside a block: one LDS word, bumped by lane 0 of a wave and broadcast
+#ifndef FRAD_HOST_EMULATION
+#define FRAD_WAVE_LDS_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define FRAD_WAVE_BCAST0(x) ((unsigned)__builtin_amdgcn_readfirstlane((int)(x)))
+#define FRAD_WAVE_SLEEP(n) __builtin_amdgcn_s_sleep(n)
+#else
+#define FRAD_WAVE_LDS_ADD(p, v) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
+#define FRAD_WAVE_BCAST0(x) ((unsigned)__shfl((unsigned long long)(x), 0, 64))
+#define FRAD_WAVE_SLEEP(n) ((void)0)
+#endif
+__device__ __forceinline__ long long wave_next_unit(unsigned* ctr) {
+    unsigned v = 0;
+    if ((threadIdx.x & 63) == 0) v = FRAD_WAVE_LDS_ADD(ctr, 1u);
+    return (long long)FRAD_WAVE_BCAST0(v);
+}
 
 #ifndef FRAD_HOST_EMULATION
-#define FRAD_WAVE_BOUNDS __launch_bounds__(256, 1)
+#define FRAD_WAVE_BOUNDS __launch_bounds__(64 * kWaveWaves, 2)
 #else
 #define FRAD_WAVE_BOUNDS
 #endif
@@ -106,11 +143,79 @@ __device__ __forceinline__ void half_wave_max_u64(u64 v, u64& lo, u64& hi) {
 #endif
 }
 
+// running max of |v| in one instruction (fmax(fm, fabs(v)) costs two: the compiler canonicalises the operand first)
+__device__ __forceinline__ void absmax_acc(double& fm, double v) {
+#ifdef FRAD_HOST_EMULATION
+    fm = fmax(fm, fabs(v));
+#else
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(fm) : "v"(fm), "v"(v));
+#endif
+}
+
+// bytes of `v` picked by a v_perm_b32 selector (selector bytes 4..7 address v's bytes 0..3)
+__device__ __forceinline__ uint32_t wave_perm(uint32_t v, uint32_t sel) {
+#ifdef FRAD_HOST_EMULATION
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) { const uint32_t s = (sel >> (8 * i)) & 0xffu; r |= (s >= 4 && s < 8 ? (v >> (8 * (s - 4))) & 0xffu : 0u) << (8 * i); }
+    return r;
+#else
+    return __builtin_amdgcn_perm(v, 0u, sel);
+#endif
+}
+
+// EB-bit element at bit `shift` of `word` -> compute type, format CODE (cvt_pcm_c semantics, normalisation deferred)
+template <int CODE, bool RAW, int EB>
+__device__ __forceinline__ double wave_elem(uint32_t word, int shift) {
+    constexpr int kind = CODE >> 3, be = CODE & 1;
+    if constexpr (EB == 32) {
+        return cvt_pcm_c<double, CODE, RAW, true>((u64)word);
+    } else if constexpr (kind == 1 && !be) {                 // signed little-endian: one v_bfe_i32 + one conversion
+#ifdef FRAD_HOST_EMULATION
+        const int s = (int)((word >> shift) << (32 - EB)) >> (32 - EB);
+#else
+        const int s = __builtin_amdgcn_sbfe((int)word, (unsigned)shift, (unsigned)EB);
+#endif
+        return (double)s;
+    } else {
+#ifdef FRAD_HOST_EMULATION
+        const uint32_t r = (word >> shift) & ((1u << EB) - 1u);
+#else
+        const uint32_t r = __builtin_amdgcn_ubfe(word, (unsigned)shift, (unsigned)EB);
+#endif
+        return cvt_pcm_c<double, CODE, RAW, true>((u64)r);
+    }
+}
+
 // =============================================================================================
-// encode: PCM -> payload.  grid = min(ceil(units / 4), CUs), block = 256 (4 independent waves).
+// encode: PCM -> payload.  grid = min(ceil(units / 7), CUs), block = 448 (7 independent waves).
 // unit = one frame (CC == 2) or a pair of frames 2u, 2u+1 (CC == 1).
 // Requires: pcm 16-byte aligned, frame byte stride % 16 == 0, payload 16-byte aligned, payload_stride % 16 == 0.
+//
+// The wave's 17 KiB of LDS, by phase:
+//   [8 KiB, 16 KiB)  raw PCM of the unit, brought in by LDS-DMA (global_load_lds_dwordx4: no registers) -- 1- and 2-byte
+//                    samples.  Issued for the NEXT unit as soon as the exchange has been consumed, so it lands during
+//                    pass 2, the pair step and the stores.  4- and 8-byte samples are loaded per element at the top of
+//                    the unit instead (the SIMD's other wave covers the latency).
+//   [0, 17 KiB)      the two exchange planes (after the raw bytes have been read into registers)
+//   [0, 8 KiB)       payload staging, two buffers of four 1 KiB rows: the pair jobs run in NB groups, each of which
+//                    completes four 1 KiB pieces of the payload (bins [g B, (g+1) B), their mirror images below M,
+//                    the same above M, and the mirror below N; B = 512 / NB bins); the pieces go to LDS in payload
+//                    byte order, come back as 16 bytes per lane and leave as four coalesced 1 KiB stores -- stores are
+//                    spread over the whole pair step instead of ending the unit in one burst.
+// Every table / LDS read is issued a batch ahead of its use (explicit double buffering between scheduling fences):
+// with two waves per SIMD an LDS round trip (hundreds of cycles behind the other waves' bursts) is otherwise exposed.
 // =============================================================================================
+#define FRAD_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef FRAD_WAVE_TWB
+#define FRAD_WAVE_TWB 4
+#endif
+#ifndef FRAD_WAVE_JOBFENCE
+#define FRAD_WAVE_JOBFENCE 1
+#endif
+#ifndef FRAD_WAVE_PRB
+#define FRAD_WAVE_PRB 4
+#endif
+
 template <int LG, int CC, int BITS>
 __global__ void FRAD_WAVE_BOUNDS
 k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload, double* absmax,
@@ -121,207 +226,385 @@ k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
     static_assert(CC == 1 || CC == 2, "channels");
     constexpr int RAWB = N * ISZ * CC;                 // raw bytes of one frame
     constexpr int FPW = 2 / CC;                        // frames per wave
-    constexpr int NPF = RAWB * FPW / 1024;             // 16-byte chunks per lane and unit (= 4 ISZ)
-    constexpr int PAYB = N * CC * NB;                  // payload bytes of one frame
-    constexpr int NST = PAYB * FPW / 1024;             // 16-byte store chunks per lane (= 4 NB)
     constexpr int QB = 4 * CC * ISZ;                   // bytes of four consecutive sample-frames
-    static_assert(RAWB * FPW <= kWaveBufBytes && PAYB * FPW <= kWaveBufBytes, "one unit fits the wave's LDS buffer");
+    constexpr bool STAGED = RAWB * FPW <= 8192;        // raw bytes through LDS (else: per-element global loads)
+    constexpr int RAWOFF = 8192;                       // where the raw bytes land in the wave's buffer
+    constexpr int NDMA = STAGED ? RAWB * FPW / 1024 : 0;   // 1 KiB LDS-DMA pieces per unit
+    constexpr int NG = NB;                             // groups of pair jobs = payload pieces per bin class
+    constexpr int JPG = 16 / NG;                       // jobs per group
+    constexpr int BPC = 512 / NB;                      // bins per 1 KiB piece (per frame: 512 CC bytes)
+    constexpr int ES = CC * NB;                        // payload bytes per bin
     FRAD_DYN_SMEM(smem);
+    const T deferred = (T)pcm_deferred_scale(g.dtype, g.raw_be);
+    const T sc = ((T)1 / (T)(2 * N)) * deferred;             // exact power of two
     {
         cx<T>* l = reinterpret_cast<cx<T>*>(smem);
-        for (int i = threadIdx.x; i < WaveLayout::SLOTS; i += blockDim.x) l[i] = blob[i];
+        for (int i = threadIdx.x; i < WaveLayout::SLOTS; i += blockDim.x) {
+            cx<T> v = blob[i];
+            if (i >= WaveLayout::PW || i < 2) { v.x *= sc; v.y *= sc; }
+            l[i] = v;
+        }
     }
     const cx<T>* ltab = reinterpret_cast<const cx<T>*>(smem);
     const int wv = threadIdx.x >> 6;
     unsigned char* wbuf = smem + kWaveTableBytes + wv * kWaveBufBytes;
     const long long frameb = (g.frame_stride * CC) << LG;
     const long long n_units = (g.n_frames + FPW - 1) / FPW;
-    const long long stride = (long long)gridDim.x * 4;
-    const bool le = g.le != 0;
-    uint32_t pf[NPF][4];
+    // units [ub, ue) belong to this block; its waves draw them from an LDS counter (the first kWaveWaves statically)
+    const long long ub = n_units * blockIdx.x / gridDim.x, ue = n_units * (blockIdx.x + 1) / gridDim.x;
+    unsigned* ctr = reinterpret_cast<unsigned*>(smem + kWaveTableBytes + kWaveWaves * kWaveBufBytes);
+    if (threadIdx.x == 0) *ctr = (unsigned)kWaveWaves;
+    // byte-order of the stored codes as a v_perm_b32 selector (one instruction whatever the endianness)
+    const uint32_t psel = g.le ? 0x07060504u : (BITS == 16 ? 0x07070405u : 0x04050607u);
     int lane = threadIdx.x & 63;
 
     auto frame_of = [&](long long u, int h) -> long long {   // frame this lane works on (clamped for the odd mono tail)
         if constexpr (CC == 2) return u;
         else { const long long f = 2 * u + h; return f < g.n_frames ? f : g.n_frames - 1; }
     };
-    auto prefetch = [&](long long u) {
-        const int h = lane >> 5, l = lane & 31;
-        const unsigned char* src = pcm + frame_of(u, h) * frameb + (CC == 2 ? lane : l) * 16;
+    // raw bytes of unit u -> LDS.  Piece i is one wave instruction: lane t's 16 bytes land at RAWOFF + 1024 i + 16 t.
+    // CC == 2: the frame's bytes in order.  CC == 1: lanes 0-31 carry frame 2u, lanes 32-63 frame 2u+1, 512 bytes each
+    // per piece, i.e. byte b of half h's frame lives at 1024 (b >> 9) + 512 h + (b & 511).
+    auto dma_in = [&](long long u) {
+        if constexpr (STAGED) {
+            const int h = lane >> 5, l = lane & 31;
+            const unsigned char* src = pcm + frame_of(u, h) * frameb + (CC == 2 ? lane : l) * 16;
 #pragma unroll
-        for (int i = 0; i < NPF; ++i) load_words<4>(src + (long long)i * (CC == 2 ? 1024 : 512), pf[i]);
+            for (int i = 0; i < NDMA; ++i) {
+#ifdef FRAD_HOST_EMULATION
+                *reinterpret_cast<v4u*>(wbuf + RAWOFF + i * 1024 + lane * 16) = *reinterpret_cast<const v4u*>(src + i * (CC == 2 ? 1024 : 512));
+#else
+#ifndef FRAD_X_NODMA
+                __builtin_amdgcn_global_load_lds(FRAD_GCPTR(void, src + i * (CC == 2 ? 1024 : 512)),
+                                                 (__attribute__((address_space(3))) void*)(wbuf + RAWOFF + i * 1024), 16, 0, 0);
+#endif
+#endif
+            }
+        }
+    };
+    auto raw_at = [&](int h, int b) -> int {                  // LDS offset of byte b (a compile-time multiple of QB plus a lane term) of half h's frame
+        if constexpr (CC == 2) return RAWOFF + b;
+        else return RAWOFF + 1024 * (b >> 9) + 512 * h + (b & 511);
     };
 
-    const T deferred = (T)pcm_deferred_scale(g.dtype, g.raw_be);
-    const T sc = ((T)1 / (T)(2 * N)) * deferred, sc2 = (K<T>::s2 / (T)(2 * N)) * deferred;
-    long long u = (long long)blockIdx.x * 4 + wv;
-    if (u < n_units) prefetch(u);
-    __syncthreads();                                          // tables are in LDS
-    while (u < n_units) {
+    long long u = ub + wv;
+    if (u < ue) dma_in(u);
+    __syncthreads();                                          // tables and counter are in LDS (the barrier's fence also retires the first DMA)
+    FRAD_STAMP_DECL;
+    while (u < ue) {
         lane = threadIdx.x & 63; FRAD_OPAQUE(lane);           // per-lane addresses are rebuilt each unit (no LICM register hoard)
         const int h = lane >> 5, l = lane & 31;
-        // ---- stage the raw bytes --------------------------------------------------------------
-        {
-            unsigned char* dst = wbuf + (CC == 2 ? lane * 16 : h * RAWB + l * 16);
+        const long long next = ub + wave_next_unit(ctr);      // (needed half a unit later, for the DMA)
+        cx<T> z[32];                                          // z[j] = packed sequence point l + 32 j of this lane's channel
+        const cx<T>* tw = ltab + WaveLayout::TW1 + l;
+        constexpr int TWB = FRAD_WAVE_TWB;                    // rows of TW1 per twiddle batch (double buffered)
+        cx<T> twb[2][TWB];
+        auto tw_load = [&](int b) {
 #pragma unroll
-            for (int i = 0; i < NPF; ++i) {
-                v4u v = {pf[i][0], pf[i][1], pf[i][2], pf[i][3]};
-                *reinterpret_cast<v4u*>(dst + i * (CC == 2 ? 1024 : 512)) = v;
+#ifdef FRAD_X_NOTW
+            for (int i = 0; i < TWB; ++i) twb[b & 1][i] = cx<T>{sc, deferred};
+#else
+            for (int i = 0; i < TWB; ++i) if (TWB * b + i > 0) twb[b & 1][i] = tw[(TWB * b + i) * 32];
+#endif
+        };
+        if constexpr (STAGED) {
+#ifndef FRAD_HOST_EMULATION
+            // this unit's DMA was issued before the previous unit's 4 NB row stores: vector-memory operations retire
+            // in order, so at most that many may still be in flight
+            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(4 * NB) : "memory");
+#endif
+            FRAD_STAMP(0);
+            team_sync<64>();
+#ifdef FRAD_X_NOCOMPUTE
+            {
+                dma_in(next < ue ? next : u);
+                const long long f = CC == 2 ? u : 2 * u + h;
+                unsigned char* dstf = payload + f * g.payload_stride + lane * 16;
+#pragma unroll
+                for (int gi = 0; gi < 16; ++gi) {
+                    const v4u row = *reinterpret_cast<const v4u*>(wbuf + RAWOFF + (gi & 7) * 1024 + lane * 16);
+                    *FRAD_GPTR(v4u, dstf + gi * 1024) = row;
+                }
+                team_sync<64>();
+                u = next;
+                continue;
             }
-        }
-        const long long next = u + stride;
-        if (next < n_units) prefetch(next);                   // lands during the transform
-        team_sync<64>();
-        // ---- Makhoul pairs -> z[j] = z_packed[l + 32 j] ------------------------------------------
-        cx<T> z[32];
-        dispatch_pcm<LG>(g.dtype, g.raw_be, [&](auto code_tag, auto raw_tag) {
-            constexpr int CODE = decltype(code_tag)::value;
-            constexpr bool RAW = decltype(raw_tag)::value != 0;
-            const unsigned char* fb = wbuf + (CC == 1 ? h * RAWB : 0);
-            if constexpr (QB <= 16) {
-                // whole quads: lanes read consecutive QB-byte groups (conflict-free), elements are picked by shifts
-                constexpr int NW = QB / 4;
-                constexpr int EB = 8 * ISZ;                     // bits per element
+#endif
+            // ---- Makhoul pairs: whole quads (consecutive lanes read consecutive QB-byte groups) ----
+            dispatch_pcm<LG>(g.dtype, g.raw_be, [&](auto code_tag, auto raw_tag) {
+                constexpr int CODE = decltype(code_tag)::value;
+                constexpr bool RAW = decltype(raw_tag)::value != 0;
+                constexpr int NW = QB / 4, EB = 8 * ISZ;
                 const int hs = (CC == 2 ? h * EB : 0);
                 auto elem = [&](const uint32_t (&w)[NW], int r) -> T {
-                    const int bit = r * CC * EB;                // static part
-                    uint32_t raw;
-                    if constexpr (EB == 32) raw = w[bit >> 5];
-                    else raw = (w[bit >> 5] >> ((bit & 31) + hs)) & ((1u << EB) - 1u);
-                    return cvt_pcm_c<T, CODE, RAW, true>((u64)raw);
+                    const int bit = r * CC * EB;                // static part of the element's bit offset
+                    return wave_elem<CODE, RAW, EB>(w[bit >> 5], (bit & 31) + hs);
                 };
-                const unsigned char* p0 = fb + l * QB;
-                const unsigned char* p1 = fb + (31 - l) * QB;
+                // quad q lives at frame byte q QB; lane l takes q = l + 32 j (j < 16) and q = (31 - l) + 32 (31 - j)
+                const unsigned char* p0 = wbuf + raw_at(h, 0) + l * QB;
+                const unsigned char* p1 = wbuf + raw_at(h, 0) + (31 - l) * QB;
+                uint32_t wq[2][8][NW];
+                auto quads = [&](int b) {                      // batch b: quads j = 8 b .. 8 b + 7
 #pragma unroll
-                for (int j = 0; j < 32; ++j) {
-                    uint32_t w[NW];
-                    const unsigned char* p = j < 16 ? p0 + j * 32 * QB : p1 + (31 - j) * 32 * QB;
-                    if constexpr (NW == 1) w[0] = *reinterpret_cast<const uint32_t*>(p);
-                    else if constexpr (NW == 2) { const v2u v = *reinterpret_cast<const v2u*>(p); w[0] = v[0]; w[1] = v[1]; }
-                    else { const v4u v = *reinterpret_cast<const v4u*>(p); w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3]; }
-                    z[j] = j < 16 ? cx<T>{elem(w, 0), elem(w, 2)} : cx<T>{elem(w, 3), elem(w, 1)};
-                }
-            } else {
-                // wide elements (4 or 8 bytes, QB = 32 / 64): one LDS read per element
-                auto elem = [&](int n) -> T {
-                    const unsigned char* p = fb + ((long long)(n * CC + (CC == 2 ? h : 0)) << LG);
-                    u64 raw;
-                    if constexpr (LG == 2) raw = *reinterpret_cast<const uint32_t*>(p);
-                    else { const v2u v = *reinterpret_cast<const v2u*>(p); raw = (u64)v[0] | ((u64)v[1] << 32); }
-                    return cvt_pcm_c<T, CODE, RAW, true>(raw);
+                    for (int i = 0; i < 8; ++i) {
+                        const int j = 8 * b + i;
+                        const int qb = (j < 16 ? j : 31 - j) * 32 * QB;        // frame byte of the quad, without the lane term
+                        const unsigned char* p = (j < 16 ? p0 : p1) + (raw_at(0, qb) - raw_at(0, 0));
+                        uint32_t (&w)[NW] = wq[b & 1][i];
+                        if constexpr (NW == 1) w[0] = *reinterpret_cast<const uint32_t*>(p);
+                        else if constexpr (NW == 2) { const v2u v = *reinterpret_cast<const v2u*>(p); w[0] = v[0]; w[1] = v[1]; }
+                        else { const v4u v = *reinterpret_cast<const v4u*>(p); w[0] = v[0]; w[1] = v[1]; w[2] = v[2]; w[3] = v[3]; }
+                    }
                 };
+                quads(0);
+                FRAD_FENCE();
 #pragma unroll
-                for (int j = 0; j < 32; ++j) {
-                    const int q = j < 16 ? l + 32 * j : (31 - l) + 32 * (31 - j);
-                    z[j] = j < 16 ? cx<T>{elem(4 * q), elem(4 * q + 2)} : cx<T>{elem(4 * q + 3), elem(4 * q + 1)};
+                for (int b = 0; b < 4; ++b) {
+                    if (b < 3) quads(b + 1); else tw_load(0);  // the next batch (or the first twiddles) is in flight while this one is converted
+                    FRAD_FENCE();
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int j = 8 * b + i;
+                        z[j] = j < 16 ? cx<T>{elem(wq[b & 1][i], 0), elem(wq[b & 1][i], 2)} : cx<T>{elem(wq[b & 1][i], 3), elem(wq[b & 1][i], 1)};
+                    }
+                    FRAD_FENCE();
                 }
-            }
-        });
-        team_sync<64>();                                       // raw bytes consumed: the buffer may be overwritten
-        // ---- pass 1: DFT over j, twiddle, exchange ---------------------------------------------
-        cx<T>* xb = reinterpret_cast<cx<T>*>(wbuf) + h * M;
-        {
-            cx<T> lo[16], hi[16], e[16], o[16];
+            });
+            team_sync<64>();                                   // raw bytes consumed: the buffer may be overwritten
+        } else {
+            // ---- wide elements: one global load per element, no staging ---------------------------
+            const unsigned char* fb = pcm + frame_of(u, h) * frameb + (CC == 2 ? (h << LG) : 0);
+            dispatch_pcm<LG>(g.dtype, g.raw_be, [&](auto code_tag, auto raw_tag) {
+                constexpr int CODE = decltype(code_tag)::value;
+                constexpr bool RAW = decltype(raw_tag)::value != 0;
+                constexpr int G = LG == 3 ? 8 : 16;            // element pairs per group of loads in flight
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { lo[i] = z[i]; hi[i] = z[i + 16]; }
-            dif32_stage<false>(lo, hi, e, o);
-            dft<16, false>(e);                                 // B[2 i]
-            dft<16, false>(o);                                 // B[2 i + 1]
-            const cx<T>* tw = ltab + WaveLayout::TW1 + l;
+                for (int j0 = 0; j0 < 32; j0 += G) {
+                    u64 raw[G][2];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const cx<T> te = i == 0 ? e[0] : cmul(e[i], tw[(2 * i) * 32]);
-                const cx<T> to = cmul(o[i], tw[(2 * i + 1) * 32]);
-                xb[xslot(2 * i, l)] = te;
-                xb[xslot(2 * i + 1, l)] = to;
+                    for (int jj = 0; jj < G; ++jj) {
+                        const int j = j0 + jj;
+                        const int q = j < 16 ? l + 32 * j : (31 - l) + 32 * (31 - j);
+                        const unsigned char* p = fb + (((long long)(4 * q) * CC) << LG);
+                        constexpr int RS = CC << LG;           // bytes per sample-frame
+                        raw[jj][0] = load_raw(p + (j < 16 ? 0 : 3) * RS, LG);
+                        raw[jj][1] = load_raw(p + (j < 16 ? 2 : 1) * RS, LG);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < G; ++jj)
+                        z[j0 + jj] = cx<T>{cvt_pcm_c<T, CODE, RAW, true>(raw[jj][0]), cvt_pcm_c<T, CODE, RAW, true>(raw[jj][1])};
+                    FRAD_FENCE();
+                }
+            });
+            tw_load(0);
+            FRAD_FENCE();
+        }
+        FRAD_STAMP(1);
+        // ---- pass 1: DFT over j --------------------------------------------------------------------
+        cx<T> e[16], o[16];
+        dif32_stage<false>(z, e, o);
+        dft<16, false>(e);                                     // B[2 i]     (row k2 = 2 i of the exchange)
+        dft<16, false>(o);                                     // B[2 i + 1]
+        FRAD_FENCE();
+        FRAD_STAMP(2);
+        // ---- twiddle W_1024^(l k2) a batch of rows at a time; real parts go straight to the exchange plane -----
+        T* pl = reinterpret_cast<T*>(wbuf) + h * kWavePlaneSlots;
+        T* plw = pl + 2 * (l & 15) + (l >> 4);                 // this lane's column (writer side)
+#pragma unroll
+        for (int b = 0; b < 32 / TWB; ++b) {
+            if (b < 32 / TWB - 1) tw_load(b + 1);
+            FRAD_FENCE();
+#pragma unroll
+            for (int i = 0; i < TWB; ++i) {
+                const int k2 = TWB * b + i;
+                cx<T>& v = (k2 & 1) ? o[k2 >> 1] : e[k2 >> 1];
+                if (k2 > 0) v = cmul(v, twb[b & 1][i]);
+#ifndef FRAD_X_NOEXCH
+                plw[34 * k2] = v.x;
+#endif
             }
+            FRAD_FENCE();
         }
         team_sync<64>();
-        // ---- pass 2: even half of residue a = l, odd half of residue b = -l ----------------------
+        // ---- pass 2 inputs: even half of residue a = l (sums), odd half of residue b = -l (differences) ------
         cx<T> E[16], O[16];
         {
-            const int b = (32 - l) & 31;
-            cx<T> lo[16], hi[16];
+            const int bb = (32 - l) & 31;
+            const v2d* ra = reinterpret_cast<const v2d*>(pl + 34 * l);
+            const v2d* rb = reinterpret_cast<const v2d*>(pl + 34 * bb);
+            constexpr int PRB = FRAD_WAVE_PRB, NQ = 16 / PRB;  // pairs per batch; batches per row
+            v2d pr[2][PRB];
+            auto pairs = [&](int q) {                          // batch q: the first NQ cover row a, the rest row b
 #pragma unroll
-            for (int n = 0; n < 16; ++n) { lo[n] = xb[xslot(l, n)]; hi[n] = xb[xslot(l, n + 16)]; }
+                for (int i = 0; i < PRB; ++i) pr[q & 1][i] = (q < NQ ? ra : rb)[PRB * (q % NQ) + i];
+            };
+            auto plane = [&](auto comp) {                      // comp: 0 = real parts, 1 = imaginary parts
+                constexpr int Y = decltype(comp)::value;
+                pairs(0);
+                FRAD_FENCE();
 #pragma unroll
-            for (int n = 0; n < 16; ++n) E[n] = lo[n] + hi[n];
+                for (int q = 0; q < 2 * NQ; ++q) {
+                    if (q < 2 * NQ - 1) pairs(q + 1);
+                    FRAD_FENCE();
 #pragma unroll
-            for (int n = 0; n < 16; ++n) { lo[n] = xb[xslot(b, n)]; hi[n] = xb[xslot(b, n + 16)]; }
+                    for (int i = 0; i < PRB; ++i) {
+                        const int n = PRB * (q % NQ) + i;
+                        const v2d v = pr[q & 1][i];            // (y[n], y[n + 16])
+                        if (q < NQ) { if constexpr (Y == 0) E[n].x = v[0] + v[1]; else E[n].y = v[0] + v[1]; }
+                        else { if constexpr (Y == 0) O[n].x = v[0] - v[1]; else O[n].y = v[0] - v[1]; }
+                    }
+                    FRAD_FENCE();
+                }
+            };
+#ifdef FRAD_X_NOEXCH
 #pragma unroll
-            for (int n = 0; n < 16; ++n) O[n] = lo[n] - hi[n];
-            tw32_apply<false>(O);
-            dft<16, false>(E);                                 // E[u] = Z[l + 64 u]
-            dft<16, false>(O);                                 // O[u] = Z[b + 32 (2 u + 1)]
+            for (int n = 0; n < 16; ++n) { E[n] = e[n]; O[n] = o[n]; }
+#else
+            plane(ic<0>{});
+            team_sync<64>();
+#pragma unroll
+            for (int k2 = 0; k2 < 32; ++k2) plw[34 * k2] = ((k2 & 1) ? o[k2 >> 1] : e[k2 >> 1]).y;
+            team_sync<64>();
+            plane(ic<1>{});
+#endif
         }
-        team_sync<64>();                                       // exchange consumed: the buffer takes the payload image
-        // ---- DCT pair step on registers, storage codes to their payload position ---------------
+#ifndef FRAD_HOST_EMULATION
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every plane read has returned: the DMA may overwrite the planes
+#endif
+        team_sync<64>();
+        FRAD_STAMP(3);
+        FRAD_FENCE();
+        dma_in(next < ue ? next : u);                          // raw landing zone is free from here on (no branch: the last unit re-reads itself)
+        FRAD_FENCE();
+        // ---- pair-step tables of the first group, then pass 2 proper -----------------------------------
+        // group g (processed from NG - 1 down to 0) holds jobs t and 15 - t for t in [g JPG / 2, (g + 1) JPG / 2)
+        // pair-step tables (w_k, g_k of one job), fetched one job ahead of their use (double buffered)
+        cx<T> ptab[2][2];
+        auto job_slot = [](int g, int i) -> int { const int t = g * (JPG / 2) + (i >> 1); return (i & 1) ? 15 - t : t; };
+        auto ptab_load = [&](int g, int i) {                   // job i of group g (jobs run g = NG - 1 .. 0, i = 0 .. JPG - 1)
+            const int s = job_slot(g, i);
+#ifdef FRAD_X_NOPTAB
+            ptab[i & 1][0] = cx<T>{sc, deferred}; ptab[i & 1][1] = cx<T>{deferred, sc};
+#else
+            ptab[i & 1][0] = ltab[WaveLayout::PW + s * 32 + l];
+            ptab[i & 1][1] = ltab[WaveLayout::PG + s * 32 + l];
+#endif
+        };
+        dft<16, false>(E);                                     // E[u] = Z[l + 64 u]
+        FRAD_FENCE();
+        tw32_apply<false>(O);
+        dft<16, false>(O);                                     // O[u] = Z[b + 32 (2 u + 1)]
+        FRAD_FENCE();
+        ptab_load(NG - 1, 0);
+        FRAD_FENCE();
+        FRAD_STAMP(4);
+        // ---- DCT pair step on registers; storage codes to the staging rows, rows to HBM, group by group -------
         const bool lane0 = (l == 0);
-        unsigned char* img = wbuf + (CC == 1 ? h * PAYB : 0);
-        const int cofs = (CC == 2 ? h : 0);
+        const long long f = CC == 2 ? u : 2 * u + h;
+        const bool live = f < g.n_frames;
+        unsigned char* dstf = payload + (live ? f : 0) * g.payload_stride + (CC == 2 ? lane : l) * 16;
         double fm = 0.0;
         bool nan = false;
-        auto put = [&](int k, T v) {                          // X[k] of this lane's channel
-            fm = fmax(fm, fabs(v));
-            nan |= (v != v);
-            unsigned char* p = img + (k * CC + cofs) * NB;
+        auto code_store = [&](unsigned char* p, T v) {         // one storage code at its payload position inside a staging row
+            absmax_acc(fm, v);
+            if constexpr (LG == 3) nan |= (v != v);            // only float64 PCM can carry NaN / Inf in
             if constexpr (BITS == 32) {
-                const uint32_t c = f2u((float)v);
-                *reinterpret_cast<uint32_t*>(p) = le ? c : bswap32(c);
+                *reinterpret_cast<uint32_t*>(p) = wave_perm(f2u((float)v), psel);
             } else if constexpr (BITS == 16) {
-                const uint32_t c = f64_to_f16_bits(v);
-                *reinterpret_cast<unsigned short*>(p) = (unsigned short)(le ? c : bswap16(c));
+                *reinterpret_cast<unsigned short*>(p) = (unsigned short)wave_perm(f64_to_f16_bits(v), psel);
             } else {
-                const u64 c = le ? d2u(v) : bswap64(d2u(v));
-                v2u w = {(uint32_t)c, (uint32_t)(c >> 32)};
+                const u64 c = d2u(v);
+                const uint32_t lo = (uint32_t)c, hi = (uint32_t)(c >> 32);
+                v2u w;
+                if (g.le) { w[0] = lo; w[1] = hi; } else { w[0] = wave_perm(hi, psel); w[1] = wave_perm(lo, psel); }
                 *reinterpret_cast<v2u*>(p) = w;
             }
         };
+        // staging: buffer (g & 1) = 4 rows of 1 KiB: bin classes A = [0, 512), B = [512, 1024) (descending with g),
+        // C = [1024, 1536), D = [1536, 2048) (descending).  Inside a row: payload byte order of the piece.
+        int hq = h, lq = l;
+        FRAD_OPAQUE(hq); FRAD_OPAQUE(lq);                     // (the staging addresses are built here, not hoisted above pass 2)
+        unsigned char* stg = wbuf + (CC == 2 ? hq * NB : hq * 512);
+        const int la = lq * ES, lb = (lane0 ? 32 : 64 - lq) * ES;             // bin offsets (bytes) of the two job kinds
+        auto row_of = [&](int g, int cls) -> unsigned char* { return stg + (g & 1) * 4096 + cls * 1024; };
         auto sel = [&](cx<T> a, cx<T> b) { return cx<T>{lane0 ? a.x : b.x, lane0 ? a.y : b.y}; };
-        // lane 0 only: the self-paired bin k = 512 (its values replace the out-of-range / duplicate outputs of k = 0)
-        cx<T> S512;
-        {
+        // lane 0 only: the self-paired bin k = 512 gives X[512] and X[1536], the lowest bins of classes B and D: they
+        // belong to the rows of group NG - 1, which is processed first
+        if (lane0) {
             const cx<T> zk = E[8], zp = conj(E[8]);
             const cx<T> p = cmul(zk + zp, ltab[WaveLayout::TW1 + 0]), q = cmul(zk - zp, ltab[WaveLayout::TW1 + 1]);
-            S512 = p + q;
+            const cx<T> S = p + q;
+            code_store(row_of(NG - 1, 1), S.x);
+            code_store(row_of(NG - 1, 3), -S.y);
         }
-        const int klo = l, khi = lane0 ? 992 : 1024 - l;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            // slot s < 8 : k = l + 64 s       , Z[k] = E[s]     , Z[M-k] = O[15-s]   (lane 0: E[(16-s) & 15])
-            // slot s >= 8: k = M - l - 64 s   , Z[k] = O[15-s]  , Z[M-k] = E[s]      (lane 0: k = 992 - 64 s, Z[M-k] = O[s])
-            const int k = s < 8 ? klo + 64 * s : khi - 64 * s;
-            const cx<T> zk = s < 8 ? E[s] : O[15 - s];
-            const cx<T> zm = s < 8 ? sel(E[(16 - s) & 15], O[15 - s]) : sel(O[s], E[s]);
-            const cx<T> zp = conj(zm);
-            const cx<T> p = cmul(zk + zp, ltab[WaveLayout::PW + s * 32 + l]), q = cmul(zk - zp, ltab[WaveLayout::PG + s * 32 + l]);
-            const cx<T> S = p + q, D = p - q;
-            if (s == 0) {
-                put(k, S.x * sc);
-                put(lane0 ? 1536 : N - k, (lane0 ? -S512.y : -S.y) * sc);
-                put(M - k, (D.x - D.y) * sc2);
-                put(lane0 ? 512 : M + k, lane0 ? S512.x * sc : (D.x + D.y) * sc2);
-            } else {
-                put(k, S.x * sc);
-                put(N - k, -S.y * sc);
-                put(M - k, (D.x - D.y) * sc2);
-                put(M + k, (D.x + D.y) * sc2);
+        for (int gi = NG - 1; gi >= 0; --gi) {
+#pragma unroll
+            for (int i = 0; i < JPG; ++i) {
+                if (i + 1 < JPG) ptab_load(gi, i + 1); else if (gi > 0) ptab_load(gi - 1, 0);      // (JPG is even: the buffers keep alternating)
+                FRAD_FENCE();
+                const int s = job_slot(gi, i);
+                const int t = s < 8 ? s : 15 - s, tl = t - gi * (JPG / 2);      // position of the job's 64 bins inside the piece
+                // slot s < 8 : k = l + 64 s       , Z[k] = E[s]     , Z[M-k] = O[15-s]   (lane 0: E[(16-s) & 15])
+                // slot s >= 8: k = 64 (t+1) - l   , Z[k] = O[15-s]  , Z[M-k] = E[s]      (lane 0: k = 64 t + 32, Z[M-k] = O[s])
+                const cx<T> zk = s < 8 ? E[s] : O[15 - s];
+                const cx<T> zm = s < 8 ? sel(E[(16 - s) & 15], O[15 - s]) : sel(O[s], E[s]);
+                const cx<T> zp = conj(zm);
+                const cx<T> p = cmul(zk + zp, ptab[i & 1][0]), q = cmul(zk - zp, ptab[i & 1][1]);
+                const cx<T> S = p + q, D = p - q;              // (already scaled by 1/2N: the tables carry it)
+                const T xm = (D.x - D.y) * K<T>::s2, xp = (D.x + D.y) * K<T>::s2;
+                // byte offset of bin k inside its piece (classes A, C); classes B, D hold bin M - k / N - k at BPC - that
+                const int offa = 64 * tl * ES + (s < 8 ? la : lb);
+                unsigned char* pa = row_of(gi, 0) + offa;
+                unsigned char* pc = row_of(gi, 2) + offa;
+                unsigned char* pb = row_of(gi, 1) + BPC * ES - offa;
+                unsigned char* pd = row_of(gi, 3) + BPC * ES - offa;
+                if (s == 0) {
+                    // lane 0 holds k = 0: X[0] (class A) and X[M] = xm, which is the first bin of class C; no X[N]
+                    code_store(pa, S.x);
+                    code_store(lane0 ? pa : pb, lane0 ? S.x : xm);
+                    code_store(pc, lane0 ? xm : xp);
+                    code_store(lane0 ? pa : pd, lane0 ? S.x : -S.y);
+                } else if (tl == 0 && s < 8) {
+                    // lane 0's bins M - k and N - k sit one past the piece: first bin of the next-higher piece of their
+                    // class, i.e. of group gi - 1's rows (other buffer; those rows are still being filled)
+                    code_store(pa, S.x);
+                    code_store(lane0 ? row_of(gi - 1, 1) : pb, xm);
+                    code_store(pc, xp);
+                    code_store(lane0 ? row_of(gi - 1, 3) : pd, -S.y);
+                } else {
+                    code_store(pa, S.x);
+                    code_store(pb, xm);
+                    code_store(pc, xp);
+                    code_store(pd, -S.y);
+                }
+                FRAD_FENCE();
             }
-        }
-        team_sync<64>();
-        // ---- payload rows out ---------------------------------------------------------------------
-        {
-            const long long f = CC == 2 ? u : 2 * u + h;
-            const bool live = f < g.n_frames;
-            const unsigned char* src = wbuf + (CC == 2 ? lane * 16 : h * PAYB + l * 16);
-            unsigned char* dst = payload + (live ? f : 0) * g.payload_stride + (CC == 2 ? lane : l) * 16;
-            if (live) {
+            FRAD_FENCE();
+            team_sync<64>();
+            FRAD_FENCE();
+            // ---- the group's four rows: back as 16 bytes per lane, out as four 1 KiB stores -------------
+            {
+                v4u row[4];
 #pragma unroll
-                for (int i = 0; i < NST; ++i) {
-                    const v4u v = *reinterpret_cast<const v4u*>(src + i * (CC == 2 ? 1024 : 512));
-                    *FRAD_GPTR(v4u, dst + i * (CC == 2 ? 1024 : 512)) = v;
+                for (int c = 0; c < 4; ++c) row[c] = *reinterpret_cast<const v4u*>(wbuf + (gi & 1) * 4096 + c * 1024 + lane * 16);
+                team_sync<64>();                               // rows read: the next group may drop its stray bins into this buffer
+                // frame byte offset of the piece: class A / C ascend with g, B / D descend
+                const int oa = gi * 512 * CC, ob = 1024 * ES - (gi + 1) * 512 * CC, oc = 1024 * ES + gi * 512 * CC, od = 2048 * ES - (gi + 1) * 512 * CC;
+                const int off[4] = {oa, ob, oc, od};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {                  // (exec-masked for the dead half of an odd mono tail: the instruction count stays 4)
+#ifdef FRAD_WAVE_NOSTORE
+                    if (live && row[c][0] == 0x12345678u) *FRAD_GPTR(v4u, dstf + off[c]) = row[c];
+#else
+                    if (live) *FRAD_GPTR(v4u, dstf + off[c]) = row[c];
+#endif
                 }
             }
+            FRAD_FENCE();
+        }
+        FRAD_STAMP(5);
+        {
             u64 mx = nan ? 0x7ff8000000000000ULL : d2u(fm);   // np.max(np.abs(.)) propagates NaN
             if (absmax != nullptr) {
                 if constexpr (CC == 2) {
@@ -334,9 +617,14 @@ k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
                 }
             }
         }
-        team_sync<64>();                                       // image read: the buffer may take the next unit's raw bytes
+        team_sync<64>();
+        FRAD_STAMP(6);
+#if defined(FRAD_WAVE_STAMPS) && !defined(FRAD_HOST_EMULATION)
+        ++st_units;
+#endif
         u = next;
     }
+    FRAD_STAMP_FLUSH;
 }
 
 }  // namespace frad

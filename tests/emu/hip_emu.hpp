@@ -87,6 +87,16 @@ inline unsigned long long __shfl_xor(unsigned long long v, int mask, int /*width
     wb.arrive_and_wait();
     return r;
 }
+inline unsigned long long __shfl(unsigned long long v, int src_lane, int /*width*/) {
+    auto* b = emu::blk;
+    auto& wb = *b->wave[emu::t_idx.x / 64];
+    b->scratch[emu::t_idx.x] = v;
+    wb.arrive_and_wait();
+    const unsigned src = (emu::t_idx.x & ~63u) + (unsigned)src_lane;
+    const unsigned long long r = src < emu::b_dim.x ? b->scratch[src] : v;
+    wb.arrive_and_wait();
+    return r;
+}
 inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) {
     unsigned long long old = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
