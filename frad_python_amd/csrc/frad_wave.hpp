@@ -246,7 +246,11 @@ k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         }
     }
     const cx<T>* ltab = reinterpret_cast<const cx<T>*>(smem);
+#ifdef FRAD_HOST_EMULATION
     const int wv = threadIdx.x >> 6;
+#else
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably wave-uniform: unit numbers and frame bases stay in SGPRs
+#endif
     unsigned char* wbuf = smem + kWaveTableBytes + wv * kWaveBufBytes;
     const long long frameb = (g.frame_stride * CC) << LG;
     const long long n_units = (g.n_frames + FPW - 1) / FPW;
@@ -528,15 +532,6 @@ k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         const int la = lq * ES, lb = (lane0 ? 32 : 64 - lq) * ES;             // bin offsets (bytes) of the two job kinds
         auto row_of = [&](int g, int cls) -> unsigned char* { return stg + (g & 1) * 4096 + cls * 1024; };
         auto sel = [&](cx<T> a, cx<T> b) { return cx<T>{lane0 ? a.x : b.x, lane0 ? a.y : b.y}; };
-        // lane 0 only: the self-paired bin k = 512 gives X[512] and X[1536], the lowest bins of classes B and D: they
-        // belong to the rows of group NG - 1, which is processed first
-        if (lane0) {
-            const cx<T> zk = E[8], zp = conj(E[8]);
-            const cx<T> p = cmul(zk + zp, ltab[WaveLayout::TW1 + 0]), q = cmul(zk - zp, ltab[WaveLayout::TW1 + 1]);
-            const cx<T> S = p + q;
-            code_store(row_of(NG - 1, 1), S.x);
-            code_store(row_of(NG - 1, 3), -S.y);
-        }
 #pragma unroll
         for (int gi = NG - 1; gi >= 0; --gi) {
 #pragma unroll
@@ -579,6 +574,17 @@ k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
                     code_store(pd, -S.y);
                 }
                 FRAD_FENCE();
+            }
+            if (gi == NG - 1) {
+                // lane 0 only: the self-paired bin k = 512 gives X[512] and X[1536], the lowest bins of classes B and D: they
+                // belong to the rows of this first-processed group (done after its jobs: fewer live registers by then)
+                if (lane0) {
+                    const cx<T> zk = E[8], zp = conj(E[8]);
+                    const cx<T> p = cmul(zk + zp, ltab[WaveLayout::TW1 + 0]), q = cmul(zk - zp, ltab[WaveLayout::TW1 + 1]);
+                    const cx<T> S = p + q;
+                    code_store(row_of(NG - 1, 1), S.x);
+                    code_store(row_of(NG - 1, 3), -S.y);
+                }
             }
             FRAD_FENCE();
             team_sync<64>();
