@@ -105,15 +105,24 @@ def analogue_batch(profile: int, pcm: torch.Tensor, pcm_format: str, n_frames: i
     escalated = {}
     if check_overflow and n_frames:
         over = absmax > FLOAT_MAX[bits]                   # NaN compares False, as in the reference
-        if bool(over.any()):
+        idx = over.nonzero().flatten()                    # (one host sync: the number of offenders sizes the re-dispatch)
+        if idx.numel():
+            # the offenders again, one launch per deeper format the reference's loop would settle on (profile0.py:24-26)
             isz = itemsize_of(code)
             flat = pcm.reshape(-1).view(torch.uint8)
-            for i in over.nonzero().flatten().tolist():
-                deeper = escalate_depth(float(absmax[i]), bits)
-                start = i * stride_frames * C * isz
-                one = analogue_batch(profile, flat[start:start + N * C * isz].clone(), pcm_format, 1, N, C, deeper,
-                                     little_endian, raw_be_ints=raw_be_ints, check_overflow=False)
-                escalated[i] = (one.payload[0, :one.nbytes], deeper)
+            frame_bytes_n = N * C * isz
+            byte_idx = torch.arange(frame_bytes_n, device=pcm.device)
+            am_host = absmax[idx].cpu().tolist()
+            by_depth: dict[int, list[int]] = {}
+            for i, a in zip(idx.tolist(), am_host):
+                by_depth.setdefault(escalate_depth(float(a), bits), []).append(i)
+            for deeper, frames in by_depth.items():
+                starts = torch.tensor(frames, device=pcm.device, dtype=torch.int64) * (stride_frames * C * isz)
+                gathered = flat[(starts[:, None] + byte_idx[None, :]).reshape(-1)]     # [len(frames), N*C*isz] contiguous
+                sub = analogue_batch(profile, gathered, pcm_format, len(frames), N, C, deeper, little_endian,
+                                     raw_be_ints=raw_be_ints, check_overflow=False)
+                for j, i in enumerate(frames):
+                    escalated[i] = (sub.payload[j, :sub.nbytes], deeper)
     return EncodedBatch(out, nbytes, bits, absmax, escalated)
 
 

@@ -119,8 +119,10 @@ def test_p0_fft_sizes(be, fmt):
                 tol = (8 * EPS32 if fmt == "f32le" else 8 * EPS64) * max(ref[f][2], 1e-300) * np.log2(N)
                 assert abs(am[f] - ref[f][2]) <= tol
             # double-rounding ties: our f64 DCT and pocketfft's differ by ~1e-16 relative, which moves a
-            # float32/float16 rounding decision for about one word in 1e5..1e6
-            assert mism <= max(2, int(1e-4 * words)), (fmt, N, C, bits, mism, words)
+            # float32/float16 rounding decision for about one word in 1e5..1e6 (observed counts are printed: -s)
+            if mism:
+                print(f"[p0 ties] {be.name} {fmt} N={N} C={C} b={bits}: {mism} of {words} words differ from the oracle's")
+            assert mism <= max(2, int(1e-5 * words)), (fmt, N, C, bits, mism, words)
             # decode the ORACLE's payload with the kernel: isolates the inverse transform
             want = np.stack([r[0] for r in ref])
             dec = be.digital(0, want, F, N, C, bits, False)
