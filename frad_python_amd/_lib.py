@@ -37,6 +37,7 @@ SYMBOLS = {
     "frad_p1_digital": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "frad_crc32_frames": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "frad_p1_overlap_add": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "frad_bench_copy": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
 
@@ -101,6 +102,9 @@ class FradLib:
 
     def p1_digital(self, q, tq, n_frames, N, C, bits, srate, out, stream=0):
         self._check(self.dll.frad_p1_digital(q, tq, n_frames, N, C, bits, srate, out, stream))
+
+    def bench_copy(self, src, dst, nbytes, stream=0):
+        self._check(self.dll.frad_bench_copy(src, dst, nbytes, stream))
 
     def p1_overlap_add(self, frames, n_frames, N, C, ratio, prev_tail, out, next_tail, stream=0):
         self._check(self.dll.frad_p1_overlap_add(frames, n_frames, N, C, ratio, prev_tail, out, next_tail, stream))

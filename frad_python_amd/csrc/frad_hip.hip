@@ -142,7 +142,7 @@ FastCfg fast_cfg(int N, int C, bool f32) {
         while (cg > 1 && ((long long)cg * c.team > tmax || (size_t)cg * per_cf > (size_t)kLdsBytes)) --cg;
         if ((long long)cg * c.team > 1024 || (size_t)cg * per_cf > (size_t)kLdsBytes) return c;
         if (cg > 1 && (cg & 1)) --cg;                       // even groups keep 12-bit pairs together
-        if (const char* e = getenv("FRAD_TUNE_CG")) { const int v = atoi(e); if (v >= 1 && v <= cg && (v == 1 || !(v & 1))) cg = v; }
+        if (const char* e = tune("FRAD_TUNE_CG")) { const int v = atoi(e); if (v >= 1 && v <= cg && (v == 1 || !(v & 1))) cg = v; }
         c.cg = cg; c.fpb = 1; c.threads = cg * c.team; c.lds = (size_t)cg * per_cf; c.ok = true;
         return c;
     }
@@ -151,11 +151,11 @@ FastCfg fast_cfg(int N, int C, bool f32) {
     // such blocks (<= 80 KiB of LDS each) share a CU so that one streams while the other computes
     while ((fpb + q) * pft <= 256 && (size_t)(fpb + q) * pfl <= 80 * 1024) fpb += q;
     c.cg = C; c.fpb = fpb; c.threads = (int)(fpb * pft); c.lds = fpb * pfl; c.ok = true;
-    if (const char* e = getenv("FRAD_TUNE_FPB")) {          // tuning knobs for experiments (not part of the ABI)
+    if (const char* e = tune("FRAD_TUNE_FPB")) {          // tuning knobs for experiments (not part of the ABI)
         const int v = atoi(e);
         if (v >= q && v % q == 0 && v * pft <= 1024 && (size_t)v * pfl <= (size_t)kLdsBytes) { c.fpb = v; c.threads = (int)(v * pft); c.lds = v * pfl; }
     }
-    if (const char* e = getenv("FRAD_TUNE_LDS_PAD")) c.lds += (size_t)atoi(e);
+    if (const char* e = tune("FRAD_TUNE_LDS_PAD")) c.lds += (size_t)atoi(e);
     return c;
 }
 
@@ -310,8 +310,8 @@ int frad_p4_digital(const void* payload, int64_t payload_stride, int64_t n_frame
     const bool fast = NC >= U && aligned16(payload) && payload_stride % 16 == 0 && aligned16(pcm_out) && (NC % 2 == 0);
     // 16 bit: a pair of values per thread keeps the float64 stores contiguous (4.0 -> 5.5 TB/s); at 32 bit the unit
     // kernel is already at 5.7 TB/s and measured faster (`fast`: NC even, aligned rows)
-    const bool pairs = fast && bits == 16 && !getenv("FRAD_TUNE_NO_P4_PAIRS");
-    const bool sub12 = fast && (bits == 24 || bits == 48) && !getenv("FRAD_TUNE_NO_P4_PAIRS");   // same idea, 12-byte sub-units
+    const bool pairs = fast && bits == 16 && !tune("FRAD_TUNE_NO_P4_PAIRS");
+    const bool sub12 = fast && (bits == 24 || bits == 48) && !tune("FRAD_TUNE_NO_P4_PAIRS");   // same idea, 12-byte sub-units
     const int bpf = blocks_per_frame(pairs ? (NC / 2 + 3) / 4 : sub12 ? (NC / (96 / bits) + 3) / 4 : fast ? NC / U : NC);
     if (n_frames * bpf > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
     dim3 grid((unsigned)(n_frames * bpf));

@@ -4,8 +4,27 @@
 #pragma once
 #include "frad_kernels.hpp"
 #include <vector>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
 
 namespace frad {
+
+// FRAD_TUNE_* experiment knobs: the environment is read ONCE per variable and process, not per launch
+inline const char* tune(const char* name) {
+    static std::mutex mu;
+    static std::map<std::string, std::string> seen;
+    static std::map<std::string, bool> have;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = have.find(name);
+    if (it == have.end()) {
+        const char* e = std::getenv(name);
+        it = have.emplace(name, e != nullptr).first;
+        if (e) seen[name] = e;
+    }
+    return it->second ? seen[name].c_str() : nullptr;
+}
 
 struct Tables { void* tw = nullptr; void* post = nullptr; void* blob = nullptr; void* blob_b = nullptr; void* blob_i = nullptr; };   // blob: LDS image of the persistent kernels
 

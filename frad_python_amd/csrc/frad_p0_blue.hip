@@ -245,7 +245,7 @@ struct BlueCfg { bool ok = false; int log2l = 0, cg = 0, threads = 0, whole = 0;
 BlueCfg blue_cfg(int N, int C, int bits, bool fwd) {
     BlueCfg c;
     if (N < 96 || N > 4096) return c;                        // tiny frames: the direct product is cheaper
-    if (const char* e = getenv("FRAD_TUNE_NO_BLUE")) { if (atoi(e) != 0) return c; }   // A/B knob, not part of the ABI
+    if (const char* e = tune("FRAD_TUNE_NO_BLUE")) { if (atoi(e) != 0) return c; }   // A/B knob, not part of the ABI
     int l2 = 8;
     while ((1 << l2) < 2 * N - 1) ++l2;
     if (l2 > 13) return c;

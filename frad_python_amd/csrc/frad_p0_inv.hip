@@ -26,20 +26,5 @@ int launch_p0_inv(const FastCfg& c, dim3 grid, hipStream_t s, const unsigned cha
 #undef FRAD_GO
 }
 
-// diagnostics: what the runtime says about residency of the N = 2048 kernels at a given LDS size
-extern "C" int frad_debug_occupancy(int threads, int lds_bytes, int* blocks_inv, int* lds_per_cu, int* lds_per_block_optin, int* cus) {
-    hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, 0) != hipSuccess) return -3;
-    *lds_per_cu = (int)p.maxSharedMemoryPerMultiProcessor; *lds_per_block_optin = (int)p.sharedMemPerBlockOptin; *cus = p.multiProcessorCount;
-    allow_lds(k_p0_inv<10, 256>, (size_t)lds_bytes);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_inv, k_p0_inv<10, 256>, threads, (size_t)lds_bytes) != hipSuccess) return -3;
-    int small = 0;
-    allow_lds(k_p4_unpack_slow<0>, (size_t)lds_bytes);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&small, k_p4_unpack_slow<0>, threads, (size_t)lds_bytes) != hipSuccess) return -3;
-    *cus = small;                       // reused: blocks/CU of a tiny-register kernel at the same LDS request
-    hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_p0_inv<10, 256>)) == hipSuccess) *lds_per_block_optin = fa.numRegs;
-    return 0;
-}
 
 }  // namespace frad

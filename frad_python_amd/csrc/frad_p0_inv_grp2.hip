@@ -107,7 +107,7 @@ int go_grp2(int bits, size_t lds, dim3 grid, hipStream_t s, const unsigned char*
 
 // 1 = launched; 0 = not this kernel's geometry
 int launch_p0_inv_grp2(const FastCfg& c, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb, const Geom& g) {
-    if (getenv("FRAD_TUNE_NO_GRP2")) return 0;                                       // A/B knob, not part of the ABI
+    if (tune("FRAD_TUNE_NO_GRP2")) return 0;                                       // A/B knob, not part of the ABI
     if (g.C != 2 * c.cg || g.n_frames > 0x7fffffffLL) return 0;
     if ((reinterpret_cast<uintptr_t>(pay) & 15) || (g.payload_stride & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return 0;
     const cx<double>* tw = static_cast<const cx<double>*>(tb.tw);

@@ -17,8 +17,8 @@ int cu_count() {
     }
     return n;
 }
-bool disabled() { const char* e = getenv("FRAD_TUNE_NO_PERS"); return e && e[0] == '1'; }
-int blocks_per_cu() { const char* e = getenv("FRAD_TUNE_PERS_BPC"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 4 ? v : 1; }
+bool disabled() { const char* e = tune("FRAD_TUNE_NO_PERS"); return e && e[0] == '1'; }
+int blocks_per_cu() { const char* e = tune("FRAD_TUNE_PERS_BPC"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 4 ? v : 1; }
 
 template <typename T, typename PL, int LG, int MAXT>
 void go_fwd(const void* blob, int threads, size_t lds, int grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay,
@@ -81,7 +81,7 @@ void go_inv_unit_a(const void* blob, int cc, size_t lds, int grid, hipStream_t s
 // default: the unfused 16-16-4 inverse (plan A).  FRAD_TUNE_INV_PLAN=I selects the 4-16-16 plan with the pair step
 // fused into the first pass; measured equal within noise on MI355X (decode already runs at ~80 % of the achievable
 // HBM rate), and plan A leaves a little LDS headroom.
-bool inv_plan_a() { const char* e = getenv("FRAD_TUNE_INV_PLAN"); return !(e && (e[0] == 'I' || e[0] == 'i')); }
+bool inv_plan_a() { const char* e = tune("FRAD_TUNE_INV_PLAN"); return !(e && (e[0] == 'I' || e[0] == 'i')); }
 
 template <int BITS>
 void go_inv_unit(const void* blob, int cc, size_t lds, int grid, hipStream_t s, const unsigned char* pay, double* out, const Geom& g) {
@@ -94,10 +94,10 @@ void go_inv_unit(const void* blob, int cc, size_t lds, int grid, hipStream_t s, 
         hipLaunchKernelGGL((k_p0_inv_unit<PlanI10, BITS, 1>), dim3(grid), dim3(512), lds, s, pay, out, b, g);
     }
 }
-bool unit_sync() { const char* e = getenv("FRAD_TUNE_PERS_UNIT"); return !(e && e[0] == '0'); }
+bool unit_sync() { const char* e = tune("FRAD_TUNE_PERS_UNIT"); return !(e && e[0] == '0'); }
 
 // plan of the N = 2048 float64 kernels: B = two waves per channel-frame (4 waves/SIMD), A = one
-bool plan_b() { const char* e = getenv("FRAD_TUNE_PERS_PLAN"); return e && (e[0] == 'B' || e[0] == 'b'); }
+bool plan_b() { const char* e = tune("FRAD_TUNE_PERS_PLAN"); return e && (e[0] == 'B' || e[0] == 'b'); }
 
 }  // namespace
 
@@ -147,7 +147,7 @@ size_t pers_blob_build(int log2m, bool f32, int which, std::vector<unsigned char
 int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const unsigned char* pcm, unsigned char* pay,
                        double* am, const Tables& tb, Geom g, int ao) {
     if (disabled() || tb.blob == nullptr || c.cg != g.C || g.in_mode == 0 || g.n_valid != g.N || g.C > 8) return 0;
-    const bool n1024 = !f32 && c.log2m == 9 && lg >= 1 && lg <= 3 && g.bits != 12 && !getenv("FRAD_TUNE_NO_UNIT9");
+    const bool n1024 = !f32 && c.log2m == 9 && lg >= 1 && lg <= 3 && g.bits != 12 && !tune("FRAD_TUNE_NO_UNIT9");
     const bool geom_ok = f32 ? (c.log2m == 11 && lg == 2) : ((c.log2m == 10 && lg >= 1 && lg <= 3) || n1024);
     if (!geom_ok) return 0;
     if (!f32 && unit_sync() && !plan_b() && g.C <= 2 && g.cc_fast == g.C &&
@@ -202,7 +202,7 @@ int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const 
 int launch_p0_inv_pers(const FastCfg& c, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb, Geom g) {
     if (disabled() || tb.blob == nullptr || c.cg != g.C || (c.log2m != 10 && c.log2m != 9) || g.C > 2 || g.cc_fast != g.C || g.in_mode != g.C) return 0;
     if (c.log2m == 9) {                                       // N = 1024: unit kernel only, two blocks per CU
-        if (!unit_sync() || plan_b() || g.bits == 12 || getenv("FRAD_TUNE_NO_UNIT9")) return 0;
+        if (!unit_sync() || plan_b() || g.bits == 12 || tune("FRAD_TUNE_NO_UNIT9")) return 0;
         const int upb = 8 / g.C;
         const size_t lds = (size_t)pers_table_bytes<double, PlanA9>() + 32 + 8 * 512 * 16;
         const long long nb = (g.n_frames + upb - 1) / upb, cap = (long long)cu_count() * 2;

@@ -20,7 +20,7 @@ int wave_cu_count() {
     return n;
 }
 // experiments only (tuning knobs): read once per process
-bool wave_disabled() { static const bool d = [] { const char* e = getenv("FRAD_TUNE_NO_WAVE"); return e && e[0] == '1'; }(); return d; }
+bool wave_disabled() { static const bool d = [] { const char* e = tune("FRAD_TUNE_NO_WAVE"); return e && e[0] == '1'; }(); return d; }
 
 std::mutex g_wave_mu;
 std::map<int, void*> g_wave_blob;                    // device -> LDS image of WaveLayout
@@ -121,7 +121,7 @@ int launch_p0_fwd_wave(int lg, hipStream_t s, const unsigned char* pcm, unsigned
     const long long nb = (units + kWaveWaves - 1) / kWaveWaves, cap = wave_cu_count();
     const int grid = (int)(nb < cap ? nb : cap);
     Geom gg = g;
-    { static const int st = [] { const char* e = getenv("FRAD_TUNE_WAVE_STAGGER"); return e ? atoi(e) : 5; }(); gg.cg = st; }   // s_sleep units of the start stagger
+    { static const int st = [] { const char* e = tune("FRAD_TUNE_WAVE_STAGGER"); return e ? atoi(e) : 5; }(); gg.cg = st; }   // s_sleep units of the start stagger
     if (g.C == 2) go_fwd_wave_lg<2>(lg, blob, grid, s, pcm, pay, am, gg);
     else go_fwd_wave_lg<1>(lg, blob, grid, s, pcm, pay, am, gg);
     return 1;

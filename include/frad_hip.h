@@ -119,10 +119,12 @@ int frad_p1_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
 
 /* frad_p1_digital == fourier.profile1.digital from the decoded integers on (profile1.py:65-77):
  * dequantise, spread the 27 thresholds over the bins, inverse DCT -> float64 [n_frames, N, C].
- * With overlap_ratio > 1 it also applies the decoder's Hann cross-fade between consecutive frames of
- * the batch (decoder.py:28-46): out_ola [n_frames, N - N/ratio... see DESIGN.md] -- when `ola_out`
- * is non-NULL frame i contributes rows [0, cut) faded against frame i-1's tail (`prev_tail` for i=0,
- * may be NULL = no previous frame) and the last frame's tail is returned in `next_tail`.           */
+ *
+ * frad_p1_overlap_add == Decoder.overlap over a batch of decoded frames (decoder.py:28-46 with the Hann ramp of
+ * backend/__init__.py:3), for overlap_ratio > 1: cut = N*(ratio-1)/ratio; frame i contributes rows [0, cut) to
+ * ola_out [n_frames, cut, C], its first N - cut rows cross-faded against frame i-1's tail (`prev_tail`
+ * [N - cut, C] for i = 0, NULL = no previous frame: no fade); the last frame's tail is returned in `next_tail`
+ * [N - cut, C] for the next batch (or the flush).                                                       */
 int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32_t N, int32_t C,
                     int32_t bits, int32_t srate, double* pcm_out, void* stream);
 int frad_p1_overlap_add(const double* frames, int64_t n_frames, int32_t N, int32_t C, int32_t overlap_ratio,
@@ -133,6 +135,12 @@ int frad_p1_overlap_add(const double* frames, int64_t n_frames, int32_t N, int32
  * ASFH.write puts into a lossless frame's header (src/libfrad/tools/asfh.py:51-73), so a batch's
  * stream can be assembled without a host pass over the payload.                                   */
 int frad_crc32_frames(const void* data, int64_t stride, int64_t n_frames, int64_t nbytes, uint32_t* crc_out, void* stream);
+
+/* ---- measurement aid (not on the codec path) ----------------------------------------------------
+ * dst[0, nbytes) = src[0, nbytes): device-to-device, 16 bytes per lane, the access shape of the
+ * transform kernels.  bench.py times it as the "achievable HBM bandwidth" yardstick next to the
+ * codec kernels.  nbytes and both pointers must be multiples of 16.                                 */
+int frad_bench_copy(const void* src, void* dst, int64_t nbytes, void* stream);
 
 #ifdef __cplusplus
 }

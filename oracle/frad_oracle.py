@@ -232,6 +232,35 @@ def p0_digital(frad: bytes, fb: int, channels: int, little_endian: bool) -> np.n
     return idct_channels(_scrub(freqs))
 
 
+def p0_analogue_batch(pcm: np.ndarray, n_frames: int, N: int, C: int, bits: int, *, little_endian: bool = False,
+                      fmt: str = "s16le", workers: int = 1) -> np.ndarray:
+    """All-cores CPU baseline of bench.py: :func:`p0_analogue` over ``n_frames`` consecutive frames of
+    ``pcm`` [n_frames*N, C] in ONE scipy call per stage -- the transform runs over the channel rows of every frame at once
+    (``workers`` threads; bitwise the per-frame result: same per-row pocketfft plan) and the cast / pack is vectorised.
+    Whole-byte depths without escalation only (the bench signal never overflows).  -> uint8 [n_frames, N*C*bits/8]."""
+    if bits not in (16, 32, 64):
+        raise ValueError("batched baseline: 16 / 32 / 64-bit storage")
+    x = to_f64(pcm.reshape(n_frames, N, C), pcm_dtype(fmt))
+    rows = np.ascontiguousarray(x.transpose(0, 2, 1))                   # [F, C, N]: contiguous rows, as dct_channels feeds them
+    freqs = _dct(rows, axis=2, norm="forward", workers=workers)
+    if np.max(np.abs(freqs)) > FLOAT_MAX[bits]:
+        raise OverflowError("a frame needs a deeper format: use p0_analogue")
+    flat = np.ascontiguousarray(freqs.transpose(0, 2, 1)).reshape(n_frames, N * C)      # bin-major / channel-minor
+    e = "<" if little_endian else ">"
+    return flat.astype(e + _STORE[bits]).view(np.uint8).reshape(n_frames, -1)
+
+
+def p0_digital_batch(payload: np.ndarray, n_frames: int, N: int, C: int, bits: int, *, little_endian: bool = False,
+                     workers: int = 1) -> np.ndarray:
+    """:func:`p0_digital` over a batch of equal frames (see :func:`p0_analogue_batch`).  -> float64 [n_frames, N, C]."""
+    if bits not in (16, 32, 64):
+        raise ValueError("batched baseline: 16 / 32 / 64-bit storage")
+    e = "<" if little_endian else ">"
+    vals = np.ascontiguousarray(payload).view(e + _STORE[bits]).astype(np.float64).reshape(n_frames, N, C)
+    rows = _scrub(np.ascontiguousarray(vals.transpose(0, 2, 1)))
+    return np.ascontiguousarray(_idct(rows, axis=2, norm="forward", workers=workers).transpose(0, 2, 1))
+
+
 def p4_analogue(pcm: np.ndarray, bits: int, srate: int, little_endian: bool):
     """ref: fourier/profile4.py:14-41."""
     if bits not in DEPTHS:

@@ -14,13 +14,14 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
-EMU_LIB = os.path.join(EMU_DIR, "libfrad_emu.so")
+EMU_LIB = os.environ.get("FRAD_EMU_LIB") or os.path.join(EMU_DIR, "libfrad_emu.so")   # FRAD_EMU_LIB: the ASan build (make emu-asan)
 CSRC = os.path.join(ROOT, "frad_python_amd", "csrc")
 
 
 def build_emulator() -> str:
     """make emu (g++, thread-per-lane interpreter of the same kernel source); no-op when current."""
-    subprocess.run(["make", "-j8", "emu"], check=True, cwd=CSRC, stdout=subprocess.DEVNULL)
+    if not os.environ.get("FRAD_EMU_LIB"):
+        subprocess.run(["make", "-j8", "emu"], check=True, cwd=CSRC, stdout=subprocess.DEVNULL)
     return EMU_LIB
 
 

@@ -169,3 +169,19 @@ def test_g5_edges(g5):
     for fmt in ("s16le", "s32le", "u8", "u16le", "s8"):
         with np.errstate(all="ignore"):
             assert np.array_equal(fo.from_f64(ff, fo.pcm_dtype(fmt)), g5[f"from_f64_{fmt}"]), fmt
+
+
+def test_batched_baseline_is_bitwise_the_per_frame_oracle():
+    """bench.py's all-cores CPU line (oracle.p0_*_batch, scipy workers) == the per-frame oracle, bit for bit"""
+    from frad_python_amd import synth
+    F, N, C = 6, 2048, 2
+    raw = synth.to_pcm(synth.harmonic_mix(F * N, C, 48000, seed=9), "s16le")
+    dt = fo.pcm_dtype("s16le")
+    for bits in (16, 32, 64):
+        for le in (False, True):
+            pay = fo.p0_analogue_batch(raw, F, N, C, bits, little_endian=le, workers=4)
+            dec = fo.p0_digital_batch(pay, F, N, C, bits, little_endian=le, workers=4)
+            for f in range(F):
+                frad, idx, ch, sr = fo.p0_analogue(fo.to_f64(raw[f * N:(f + 1) * N], dt), bits, 48000, le)
+                assert pay[f].tobytes() == frad, (bits, le, f)
+                assert np.array_equal(dec[f], fo.p0_digital(frad, idx, ch, le)), (bits, le, f)

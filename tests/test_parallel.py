@@ -61,3 +61,21 @@ def test_two_rank_gloo_sharding_equals_single_rank():
     for p in procs: p.join(timeout=60)
     assert ok
     assert dt >= 0.3            # MAX over ranks: rank 1 slept
+
+
+def test_bench_launcher_starts_one_process_per_gpu():
+    """`bench.py --gpus 2` without a torch.distributed environment: the parent starts two ranks (gloo rehearsal on CPU,
+    --dry-run: rendezvous, barrier and MAX-reduce only) and rank 0 prints the one JSON line with n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["clips_rank0"] == 2048
+    assert d["ms_per_step"] >= 20.0                          # MAX over ranks: rank 1 sleeps 20 ms

@@ -57,5 +57,16 @@ for k, e in counters.items():
         # units: KiB per dispatch; FETCH_SIZE under-counts wide coalesced reads by exactly 2x on gfx950
         e["hbm_bytes_per_launch_corrected"] = int((2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024)
         e["hbm_bytes_per_launch_raw"] = int((e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024)
+# which build these counters belong to: bench.py only quotes `roofline.traffic` from a file whose kernel sources match
+import hashlib
+import subprocess
+h = hashlib.sha256()
+for f in sorted(glob.glob(os.path.join(root, "frad_python_amd", "csrc", "*.h*")) + glob.glob(os.path.join(root, "frad_python_amd", "csrc", "*.inc"))):
+    h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+try:
+    git = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip()
+except Exception:
+    git = None
+counters["_meta"] = {"tag": tag, "csrc_sha": h.hexdigest()[:16], "git": git}
 json.dump(counters, open(os.path.join(dst, f"{tag}_counters.json"), "w"), indent=1)
 print("wrote", [f for f in os.listdir(dst) if f.startswith(tag)])
