@@ -420,6 +420,7 @@ int frad_p0_digital(const void* payload, int64_t payload_stride, int64_t n_frame
     Geom g = make_geom(n_frames, N, C, N, payload_stride, bits, flags, FRAD_PCM_F64LE);
     const int ai = (aligned16(payload) && payload_stride % 16 == 0) ? 1 : 0;
     const unsigned char* in = static_cast<const unsigned char*>(payload);
+    if (launch_p0_inv_wave(s, in, pcm_out, g, ai, aligned16(pcm_out) ? 1 : 0, unit_neg)) { HIPCHK(hipGetLastError()); return FRAD_OK; }
     const FastCfg c = fast_cfg(N, C, false);
     if (c.ok) {
         Tables tb; rc = get_tables(c.log2m, false, tb);

@@ -83,6 +83,8 @@ int blue_last_hip_error();
 typedef void (*unit_root_fn)(long long, long long, long double&, long double&);      // exp(-i pi p / q)
 int launch_p0_fwd_wave(int lg, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* absmax, const Geom& g,
                        int aligned_in, int aligned_out, unit_root_fn unit);
+int launch_p0_inv_wave(hipStream_t s, const unsigned char* pay, double* out, const Geom& g, int aligned_in, int aligned_out,
+                       unit_root_fn unit);
 void wave_blob_build(std::vector<unsigned char>& bytes, unit_root_fn unit);
 void wave_clear();
 // CRC-32 tables (frad_crc.hip)

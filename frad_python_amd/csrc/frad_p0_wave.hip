@@ -22,6 +22,9 @@ int wave_cu_count() {
 // experiments only (tuning knobs): read once per process
 bool wave_disabled() { static const bool d = [] { const char* e = tune("FRAD_TUNE_NO_WAVE"); return e && e[0] == '1'; }(); return d; }
 
+// start stagger of the waves of a block, in steps of 64 cycles per (wave, block mod 8) slot (Geom::cg carries it; these kernels do not use cg)
+int wave_stagger() { static const int st = [] { const char* e = tune("FRAD_TUNE_WAVE_STAGGER"); return e ? atoi(e) : 0; }(); return st; }
+
 std::mutex g_wave_mu;
 std::map<int, void*> g_wave_blob;                    // device -> LDS image of WaveLayout
 int g_wave_hip = 0;
@@ -52,6 +55,21 @@ void go_fwd_wave_lg(int lg, const void* blob, int grid, hipStream_t s, const uns
         default: go_fwd_wave_bits<3, CC>(blob, grid, s, pcm, pay, am, g); break;
     }
 #endif
+}
+
+template <int CC, int BITS>
+void go_inv_wave(const void* blob, int grid, hipStream_t s, const unsigned char* pay, double* out, const Geom& g) {
+    allow_lds(k_p0_inv_wave<CC, BITS>, kWaveLdsBytes);
+    hipLaunchKernelGGL((k_p0_inv_wave<CC, BITS>), dim3(grid), dim3(64 * kWaveWaves), kWaveLdsBytes, s, pay, out,
+                       static_cast<const cx<double>*>(blob), g);
+}
+template <int CC>
+void go_inv_wave_bits(const void* blob, int grid, hipStream_t s, const unsigned char* pay, double* out, const Geom& g) {
+    switch (g.bits) {
+        case 16: go_inv_wave<CC, 16>(blob, grid, s, pay, out, g); break;
+        case 32: go_inv_wave<CC, 32>(blob, grid, s, pay, out, g); break;
+        default: go_inv_wave<CC, 64>(blob, grid, s, pay, out, g); break;
+    }
 }
 
 }  // namespace
@@ -121,9 +139,25 @@ int launch_p0_fwd_wave(int lg, hipStream_t s, const unsigned char* pcm, unsigned
     const long long nb = (units + kWaveWaves - 1) / kWaveWaves, cap = wave_cu_count();
     const int grid = (int)(nb < cap ? nb : cap);
     Geom gg = g;
-    { static const int st = [] { const char* e = tune("FRAD_TUNE_WAVE_STAGGER"); return e ? atoi(e) : 5; }(); gg.cg = st; }   // s_sleep units of the start stagger
+    gg.cg = wave_stagger();
+    { static const int plain = [] { const char* e = tune("FRAD_TUNE_WAVE_PLAIN_PAYLOAD"); return e ? atoi(e) : 0; }(); gg.fpb = plain; }   // (fpb is unused by these kernels)
     if (g.C == 2) go_fwd_wave_lg<2>(lg, blob, grid, s, pcm, pay, am, gg);
     else go_fwd_wave_lg<1>(lg, blob, grid, s, pcm, pay, am, gg);
+    return 1;
+}
+
+int launch_p0_inv_wave(hipStream_t s, const unsigned char* pay, double* out, const Geom& g, int ai, int ao, unit_root_fn unit) {
+    if (wave_disabled() || !wave_geometry(g.N, g.C, g.bits) || !ai || !ao) return 0;
+    if (tune("FRAD_TUNE_NO_WAVE_DEC")) return 0;
+    const void* blob = wave_blob(unit);
+    if (blob == nullptr) return 0;
+    const long long units = g.C == 2 ? g.n_frames : (g.n_frames + 1) / 2;
+    const long long nb = (units + kWaveWaves - 1) / kWaveWaves, cap = wave_cu_count();
+    const int grid = (int)(nb < cap ? nb : cap);
+    Geom gg = g;
+    gg.cg = wave_stagger();
+    if (g.C == 2) go_inv_wave_bits<2>(blob, grid, s, pay, out, gg);
+    else go_inv_wave_bits<1>(blob, grid, s, pay, out, gg);
     return 1;
 }
 

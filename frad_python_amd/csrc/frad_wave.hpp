@@ -152,6 +152,15 @@ __device__ __forceinline__ void absmax_acc(double& fm, double v) {
 #endif
 }
 
+// 16-byte store of data that is written once and not read again by this kernel (payload rows, decoded PCM): nontemporal
+__device__ __forceinline__ void stream_store(unsigned char* p, v4u v) {
+#if defined(FRAD_HOST_EMULATION) || defined(FRAD_WAVE_PLAIN_STORES)
+    *FRAD_GPTR(v4u, p) = v;
+#else
+    __builtin_nontemporal_store(v, FRAD_GPTR(v4u, p));
+#endif
+}
+
 // bytes of `v` picked by a v_perm_b32 selector (selector bytes 4..7 address v's bytes 0..3)
 __device__ __forceinline__ uint32_t wave_perm(uint32_t v, uint32_t sel) {
 #ifdef FRAD_HOST_EMULATION
@@ -206,6 +215,9 @@ __device__ __forceinline__ double wave_elem(uint32_t word, int shift) {
 // with two waves per SIMD an LDS round trip (hundreds of cycles behind the other waves' bursts) is otherwise exposed.
 // =============================================================================================
 #define FRAD_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef FRAD_WAVE_DMA_AUX
+#define FRAD_WAVE_DMA_AUX 2                     // nt: the PCM is read once
+#endif
 #ifndef FRAD_WAVE_TWB
 #define FRAD_WAVE_TWB 4
 #endif
@@ -280,7 +292,7 @@ k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
 #else
 #ifndef FRAD_X_NODMA
                 __builtin_amdgcn_global_load_lds(FRAD_GCPTR(void, src + i * (CC == 2 ? 1024 : 512)),
-                                                 (__attribute__((address_space(3))) void*)(wbuf + RAWOFF + i * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(wbuf + RAWOFF + i * 1024), 16, 0, FRAD_WAVE_DMA_AUX);
 #endif
 #endif
             }
@@ -294,6 +306,7 @@ k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
     long long u = ub + wv;
     if (u < ue) dma_in(u);
     __syncthreads();                                          // tables and counter are in LDS (the barrier's fence also retires the first DMA)
+    for (int i = (wv * 8 + (int)(blockIdx.x & 7)) * g.cg; i > 0; --i) FRAD_WAVE_SLEEP(1);      // start stagger (g.cg x 64 cycles per step; 0 = off)
     FRAD_STAMP_DECL;
     while (u < ue) {
         lane = threadIdx.x & 63; FRAD_OPAQUE(lane);           // per-lane addresses are rebuilt each unit (no LICM register hoard)
@@ -603,7 +616,7 @@ k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
 #ifdef FRAD_WAVE_NOSTORE
                     if (live && row[c][0] == 0x12345678u) *FRAD_GPTR(v4u, dstf + off[c]) = row[c];
 #else
-                    if (live) *FRAD_GPTR(v4u, dstf + off[c]) = row[c];
+                    if (CC == 2 || live) { if (g.fpb) *FRAD_GPTR(v4u, dstf + off[c]) = row[c]; else stream_store(dstf + off[c], row[c]); }
 #endif
                 }
             }
@@ -631,6 +644,315 @@ k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         u = next;
     }
     FRAD_STAMP_FLUSH;
+}
+
+
+// =============================================================================================
+// decode: payload -> float64 PCM (profile0.digital, profile0.py:46-69).  Same wave-per-unit structure, run backwards:
+//   payload words of the unit's 16 pair jobs (4 bins each), fetched straight into registers during the PREVIOUS unit's
+//     output phase (64 registers at 16- / 32-bit storage; issued before that unit's stores, so waiting for them never
+//     waits for a store)
+//   unpack + NaN/Inf scrub -> inverse DCT pair step on registers -> Z'[l + 64 u] (E) and Z'[-l + 32 (2u + 1)] (O)
+//   two inverse 16-point DFTs; the odd half takes the conjugate W_32^n
+//   ONE exchange: lane a writes Ee_a[n] to row a and Oo_(-a)[n] next to it in row -a; lane n2 reads the pair
+//     (Ee_r, Oo_r)[n2 mod 16] of every row r with one ds_read_b128 and forms Y_r = Ee_r +- Oo_r -- the last radix-2
+//     step of the 32-point inverse DFT over m, done by the reader (real plane, then imaginary plane)
+//   conjugate twiddle W_1024^(r n2), inverse 32-point DFT over r -> z[n2 + 32 n1]: this channel's packed time sequence
+//   output: slots n1 and 31 - n1 complete sample-frames [128 n1, 128 n1 + 128); four such blocks = 8 KiB go to an
+//     XOR-swizzled staging buffer in sample order (Makhoul's permutation undone by the write addresses), come back as
+//     16 bytes per lane and leave as eight coalesced 1 KiB stores -- 32 stores per unit, spread over the output phase.
+// =============================================================================================
+// a + s * b into a register of its own (the compiler's tied v_fmac would keep the result inside the 128-bit load tuple
+// that delivered a and b, i.e. four registers alive for a two-register value)
+__device__ __forceinline__ double fma_free(double s, double b, double a) {
+#ifdef FRAD_HOST_EMULATION
+    return fma(s, b, a);
+#else
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(s), "v"(b), "v"(a));
+    return r;
+#endif
+}
+template <typename T> __device__ __forceinline__ cx<T> cmulc(cx<T> a, cx<T> w) {      // a * conj(w)
+    return {fma(a.x, w.x, a.y * w.y), fma(a.y, w.x, -(a.x * w.y))};
+}
+
+template <int CC, int BITS>
+__global__ void FRAD_WAVE_BOUNDS
+k_p0_inv_wave(const unsigned char* __restrict__ payload, double* __restrict__ out, const cx<double>* __restrict__ blob, Geom g) {
+    using T = double;
+    constexpr int M = 1024, N = 2048, NB = BITS / 8;
+    static_assert(BITS == 16 || BITS == 32 || BITS == 64, "whole-byte power-of-two storage");
+    static_assert(CC == 1 || CC == 2, "channels");
+    constexpr int FPW = 2 / CC;
+    constexpr bool PF = NB <= 4;                       // the next unit's payload words are fetched across the loop edge
+    using code_t = typename std::conditional<BITS == 64, u64, uint32_t>::type;
+    FRAD_DYN_SMEM(smem);
+    {
+        cx<T>* l = reinterpret_cast<cx<T>*>(smem);
+        for (int i = threadIdx.x; i < WaveLayout::SLOTS; i += blockDim.x) l[i] = blob[i];
+    }
+    const cx<T>* ltab = reinterpret_cast<const cx<T>*>(smem);
+#ifdef FRAD_HOST_EMULATION
+    const int wv = threadIdx.x >> 6;
+#else
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#endif
+    unsigned char* wbuf = smem + kWaveTableBytes + wv * kWaveBufBytes;
+    const long long n_units = (g.n_frames + FPW - 1) / FPW;
+    const long long ub = n_units * blockIdx.x / gridDim.x, ue = n_units * (blockIdx.x + 1) / gridDim.x;
+    unsigned* ctr = reinterpret_cast<unsigned*>(smem + kWaveTableBytes + kWaveWaves * kWaveBufBytes);
+    if (threadIdx.x == 0) *ctr = (unsigned)kWaveWaves;
+    const uint32_t psel = g.le ? 0x07060504u : (BITS == 16 ? 0x07070405u : 0x04050607u);
+    int lane = threadIdx.x & 63;
+
+    auto frame_of = [&](long long u, int h) -> long long {
+        if constexpr (CC == 2) return u;
+        else { const long long f = 2 * u + h; return f < g.n_frames ? f : g.n_frames - 1; }
+    };
+    // payload words of unit u: w[s][c] = stored code of bin (k, N - k, M - k, M + k)[c] of job slot s, this lane's channel
+    code_t w[16][4];
+    auto load_words = [&](long long u, int part) {             // part p = job slots 4p .. 4p+3 (-1: all)
+        const int h = lane >> 5, l = lane & 31;
+        const bool lane0 = (l == 0);
+        // eight lane pointers (bin classes k, M + k, M - k, N - k for the two job kinds) + the slot's constant in the
+        // instruction's immediate offset
+        constexpr int ES = CC * NB;
+        const unsigned char* fp = payload + frame_of(u, h) * g.payload_stride + (CC == 2 ? h * NB : 0);
+        const int ka = l, kb = lane0 ? 32 : 64 - l;
+        const unsigned char* pA[2] = {fp + ka * ES, fp + kb * ES};                            // X[k]
+        const unsigned char* pC[2] = {fp + (M + ka) * ES, fp + (M + kb) * ES};                // X[M + k]
+        const unsigned char* pB[2] = {fp + (M - ka) * ES, fp + (M - kb) * ES};                // X[M - k]
+        const unsigned char* pD[2] = {fp + (N - ka) * ES, fp + (N - kb) * ES};                // X[N - k]
+        auto fetch = [&](const unsigned char* p) -> code_t {
+#if defined(FRAD_HOST_EMULATION) || defined(FRAD_WAVE_PLAIN_LOADS)
+            if constexpr (BITS == 16) return *FRAD_GCPTR(unsigned short, p);
+            else if constexpr (BITS == 32) return *FRAD_GCPTR(uint32_t, p);
+            else return *FRAD_GCPTR(u64, p);
+#else                                                          // read once: nontemporal (keeps the streams out of each other's way in L2 / MALL)
+            if constexpr (BITS == 16) return __builtin_nontemporal_load(FRAD_GCPTR(unsigned short, p));
+            else if constexpr (BITS == 32) return __builtin_nontemporal_load(FRAD_GCPTR(uint32_t, p));
+            else return __builtin_nontemporal_load(FRAD_GCPTR(u64, p));
+#endif
+        };
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if (part >= 0 && (s >> 2) != part) continue;
+            const int j = s < 8 ? 0 : 1, o = 64 * (s < 8 ? s : 15 - s) * ES;
+            w[s][0] = fetch(pA[j] + o);
+            if (s == 0) {                                      // lane 0 (k = 0): X[N] does not exist and X[M - 0] = X[M + 0]; it fetches
+                w[s][1] = fetch(lane0 ? fp + 1536 * ES : pD[0]);       // the self-paired bin's X[1536] and X[512] instead (job k = 512)
+                w[s][2] = fetch(lane0 ? fp + 512 * ES : pB[0]);
+            } else {
+                w[s][1] = fetch(pD[j] - o);
+                w[s][2] = fetch(pB[j] - o);
+            }
+            w[s][3] = fetch(pC[j] + o);
+        }
+    };
+    auto value = [&](code_t c) -> T {                          // stored code -> float64, NaN / Inf -> 0 (profile0.py:62-66)
+        if constexpr (BITS == 32) {
+            float f = u2f(wave_perm(c, psel));
+#ifdef FRAD_HOST_EMULATION
+            if (!std::isfinite(f)) f = 0.0f;
+#else
+            if (__builtin_amdgcn_classf(f, 0x203)) f = 0.0f;   // signalling / quiet NaN, -Inf, +Inf
+#endif
+            return (T)f;
+        } else if constexpr (BITS == 16) {
+            float f = f16_bits_to_f32(wave_perm(c, psel) & 0xffffu);
+#ifdef FRAD_HOST_EMULATION
+            if (!std::isfinite(f)) f = 0.0f;
+#else
+            if (__builtin_amdgcn_classf(f, 0x203)) f = 0.0f;
+#endif
+            return (T)f;
+        } else {
+            const uint32_t lo = (uint32_t)c, hi = (uint32_t)(c >> 32);
+            const u64 v = g.le ? c : ((u64)wave_perm(lo, psel) << 32) | wave_perm(hi, psel);
+            return ((v >> 52) & 0x7ff) == 0x7ff ? 0.0 : u2d(v);
+        }
+    };
+
+    long long u = ub + wv;
+    if constexpr (PF) { if (u < ue) load_words(u, -1); }
+    __syncthreads();                                          // tables and counter are in LDS
+    for (int i = (wv * 8 + (int)(blockIdx.x & 7)) * g.cg; i > 0; --i) FRAD_WAVE_SLEEP(1);      // start stagger (g.cg x 64 cycles per step; 0 = off)
+    while (u < ue) {
+        lane = threadIdx.x & 63; FRAD_OPAQUE(lane);
+        const int h = lane >> 5, l = lane & 31;
+        const bool lane0 = (l == 0);
+        const long long next = ub + wave_next_unit(ctr);
+        if constexpr (!PF) load_words(u, -1);
+        // ---- inverse pair step: X[k], X[N-k], X[M-k], X[M+k] -> Z'[k], Z'[M-k] -----------------------
+        cx<T> E[16], O[16];
+        {
+            cx<T> zk[16], zm[16];
+            cx<T> ptab[2][2];
+            auto ptab_load = [&](int s) {
+                ptab[s & 1][0] = ltab[WaveLayout::PW + s * 32 + l];
+                ptab[s & 1][1] = ltab[WaveLayout::PG + s * 32 + l];
+            };
+            auto inv_pair = [&](T xk, T xnk, T a, T b, cx<T> wk, cx<T> gk, cx<T>& rk, cx<T>& rm) {
+                const cx<T> uu = {xk, -xnk};
+                const cx<T> sv = {(a + b) * K<T>::s2, (b - a) * K<T>::s2};
+                const cx<T> A = cmulc(uu + sv, wk), B = cmulc(uu - sv, gk);
+                rk = A + B; rm = conj(A - B);
+            };
+            ptab_load(0);
+            FRAD_FENCE();
+            cx<T> zsp, dump;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                if (s + 1 < 16) ptab_load(s + 1);
+                FRAD_FENCE();
+                const T xa = value(w[s][0]), xd = value(w[s][1]), xb = value(w[s][2]), xc = value(w[s][3]);
+                if (s == 0) {
+                    // lane 0: k = 0 (X[N] = 0, X[M] on both sides) and, from the two borrowed words, the self-paired k = 512
+                    inv_pair(xa, lane0 ? 0.0 : xd, lane0 ? xc : xb, xc, ptab[0][0], ptab[0][1], zk[0], zm[0]);
+                    inv_pair(xb, xd, xb, xd, ltab[WaveLayout::TW1 + 0], ltab[WaveLayout::TW1 + 1], zsp, dump);
+                } else {
+                    inv_pair(xa, xd, xb, xc, ptab[s & 1][0], ptab[s & 1][1], zk[s], zm[s]);
+                }
+                FRAD_FENCE();
+            }
+            auto sel = [&](cx<T> a, cx<T> b) { return cx<T>{lane0 ? a.x : b.x, lane0 ? a.y : b.y}; };
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { E[j] = zk[j]; O[j] = zk[15 - j]; }
+#pragma unroll
+            for (int j = 8; j < 16; ++j) {
+                O[j] = sel(zm[j], zm[15 - j]);
+                E[j] = sel(j == 8 ? zsp : zm[16 - j], zm[j]);
+            }
+        }
+        FRAD_FENCE();
+        // ---- inverse 16-point DFTs over m; the odd half takes conj(W_32^n) --------------------------
+        dft<16, true>(E);
+        FRAD_FENCE();
+        dft<16, true>(O);
+        tw32_apply<true>(O);
+        FRAD_FENCE();
+        // ---- exchange: Ee to row a, Oo to row -a (next to the Ee of that row); reader forms Ee +- Oo ----
+        T* pl = reinterpret_cast<T*>(wbuf) + h * kWavePlaneSlots;
+        cx<T> Y[32];
+        {
+            const int bb = (32 - l) & 31;
+            T* wa = pl + 34 * l;
+            T* wb = pl + 34 * bb + 1;
+            const v2d* rd = reinterpret_cast<const v2d*>(pl + 2 * (l & 15));
+            const T sg = (l & 16) ? -1.0 : 1.0;
+            constexpr int PRB = FRAD_WAVE_PRB;
+            v2d pr[2][PRB];
+            auto pairs = [&](int q) {
+#pragma unroll
+                for (int i = 0; i < PRB; ++i) pr[q & 1][i] = rd[17 * (PRB * q + i)];      // row r = PRB q + i: 34 doubles = 17 pairs apart
+            };
+            auto plane = [&](auto comp) {
+                constexpr int Yc = decltype(comp)::value;
+#pragma unroll
+                for (int n = 0; n < 16; ++n) { wa[2 * n] = Yc ? E[n].y : E[n].x; wb[2 * n] = Yc ? O[n].y : O[n].x; }
+                team_sync<64>();
+                pairs(0);
+                FRAD_FENCE();
+#pragma unroll
+                for (int q = 0; q < 32 / PRB; ++q) {
+                    if (q + 1 < 32 / PRB) pairs(q + 1);
+                    FRAD_FENCE();
+#pragma unroll
+                    for (int i = 0; i < PRB; ++i) {
+                        const v2d v = pr[q & 1][i];
+                        if constexpr (Yc == 0) Y[PRB * q + i].x = fma_free(sg, v[1], v[0]); else Y[PRB * q + i].y = fma_free(sg, v[1], v[0]);
+                    }
+                    FRAD_FENCE();
+                }
+            };
+            plane(ic<0>{});
+            team_sync<64>();
+            plane(ic<1>{});
+            team_sync<64>();
+        }
+        // ---- conjugate twiddle W_1024^(r n2), inverse 32-point DFT over r -> z[n2 + 32 n1] ------------------
+        cx<T> e[16], o[16];
+        {
+            const cx<T>* tw = ltab + WaveLayout::TW1 + l;
+            constexpr int TWB = FRAD_WAVE_TWB;
+            cx<T> twb[2][TWB];
+            auto tw_load = [&](int b) {
+#pragma unroll
+                for (int i = 0; i < TWB; ++i) if (TWB * b + i > 0) twb[b & 1][i] = tw[(TWB * b + i) * 32];
+            };
+            tw_load(0);
+            FRAD_FENCE();
+#pragma unroll
+            for (int b = 0; b < 32 / TWB; ++b) {
+                if (b + 1 < 32 / TWB) tw_load(b + 1);
+                FRAD_FENCE();
+#pragma unroll
+                for (int i = 0; i < TWB; ++i) { const int r = TWB * b + i; if (r > 0) Y[r] = cmulc(Y[r], twb[b & 1][i]); }
+                FRAD_FENCE();
+            }
+            dif32_stage<true>(Y, e, o);
+            dft<16, true>(e);                                  // z[n2 + 32 (2 i)]
+            FRAD_FENCE();
+            dft<16, true>(o);                                  // z[n2 + 32 (2 i + 1)]
+            FRAD_FENCE();
+        }
+        // ---- output: four groups of four 128-sample-frame blocks through the swizzled staging buffer ---------
+        {
+            const long long f = CC == 2 ? u : 2 * u + h;
+            const bool live = f < g.n_frames;
+            int lq = l, hq = h;
+            FRAD_OPAQUE(lq); FRAD_OPAQUE(hq);
+            unsigned char* dstf = reinterpret_cast<unsigned char*>(out + (live ? f : 0) * (long long)N * CC);
+            // staging position of local sample-frame S = 4 n + r (n = lane's quad inside the block, r = 0..3), see header:
+            //   CC == 2: 16-byte rows R = S, physical row R ^ ((R >> 3) & 7), channel h in the row's half
+            //   CC == 1: 8-byte slots S of frame h (4 KiB per frame and group), physical slot S ^ (((S >> 4) & 3) << 1)
+            auto spos = [&](int n, int r) -> int {             // byte offset inside a group buffer, without the block term
+                const int S = 4 * n + r;
+                if constexpr (CC == 2) return ((S ^ ((S >> 3) & 7)) * 16) + 8 * hq;
+                else return hq * 4096 + ((S ^ (((S >> 4) & 3) << 1)) * 8);
+            };
+            const int pa0 = spos(lq, 0), pa2 = spos(lq, 2), pb3 = spos(31 - lq, 3), pb1 = spos(31 - lq, 1);
+            const int rdo = CC == 2 ? ((lane ^ ((lane >> 3) & 7)) * 16) : (hq * 4096 + ((lq ^ ((lq >> 3) & 3)) * 16));
+            constexpr int BLK = CC == 2 ? 2048 : 1024;         // bytes of one 128-sample-frame block (per frame)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                unsigned char* sb = wbuf + (gq & 1) * 8192;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n1 = 4 * gq + j, i = n1 >> 1;
+                    const cx<T> zlo = (n1 & 1) ? o[i] : e[i], zhi = (n1 & 1) ? e[15 - i] : o[15 - i];
+                    unsigned char* bp = sb + j * BLK;
+                    *reinterpret_cast<T*>(bp + pa0) = zlo.x;   // x[4 q]
+                    *reinterpret_cast<T*>(bp + pa2) = zlo.y;   // x[4 q + 2]
+                    *reinterpret_cast<T*>(bp + pb3) = zhi.x;   // x[4 q' + 3]
+                    *reinterpret_cast<T*>(bp + pb1) = zhi.y;   // x[4 q' + 1]
+                }
+                FRAD_FENCE();
+                // a quarter of the next unit's payload words per group, into the registers this group's samples have just
+                // freed (the first quarter before any store of this unit: waiting for it never waits for a store)
+                if constexpr (PF) { load_words(next < ue ? next : u, gq); }
+                team_sync<64>();
+                FRAD_FENCE();
+                // CC == 2: the group's 512 rows are 8 KiB of the frame, in order.  CC == 1: 256 rows (4 KiB) per frame.
+                unsigned char* dp = dstf + gq * (CC == 2 ? 8192 : 4096) + (CC == 2 ? lane : l) * 16;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {               // four rows at a time: 16 registers
+                    v4u row[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) row[i] = *reinterpret_cast<const v4u*>(sb + rdo + (4 * hf + i) * (CC == 2 ? 1024 : 512));
+                    if (hf == 1) team_sync<64>();              // all rows read: the buffer may be refilled (two groups from now)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)            // (CC == 2: every lane is live -- no branch, so that the compiler can count these stores
+                        if (CC == 2 || live) stream_store(dp + (4 * hf + i) * (CC == 2 ? 1024 : 512), row[i]);     //  when it waits for the loads issued before them)
+                    FRAD_FENCE();
+                }
+                FRAD_FENCE();
+            }
+        }
+        team_sync<64>();
+        u = next;
+    }
 }
 
 }  // namespace frad
