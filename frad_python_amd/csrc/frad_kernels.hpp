@@ -61,7 +61,7 @@ template <int NW> __device__ __forceinline__ void store_words(unsigned char* p, 
 #pragma unroll
     for (int i = 0; i < NW / 4; ++i) {
         v4u v = {w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
-        FRAD_GPTR(v4u, p)[i] = v;
+        FRAD_NT_STORE(v, FRAD_GPTR(v4u, p) + i);              // payload / PCM rows are written once: streaming store
     }
 }
 // element i (LG = log2 itemsize) of a little-endian word array
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) k_p4_unpack(const unsigned char* __restri
 #pragma unroll
         for (int i = 0; i < U / 2; ++i) {
             v2d v = {code_to_f64(codes[2 * i], BITS), code_to_f64(codes[2 * i + 1], BITS)};
-            FRAD_GPTR(v2d, dst + u * U)[i] = v;
+            FRAD_NT_STORE(v, FRAD_GPTR(v2d, dst + u * U) + i);
         }
     }
     if (chunk == 0)
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(256) k_p4_unpack_pairs(const unsigned char* __
         if constexpr (BITS == 16) { c0 = w[0] & 0xffffu; c1 = w[0] >> 16; if (!le) { c0 = bswap16((uint32_t)c0); c1 = bswap16((uint32_t)c1); } }
         else { c0 = w[0]; c1 = w[1]; if (!le) { c0 = bswap32((uint32_t)c0); c1 = bswap32((uint32_t)c1); } }
         v2d v = {code_to_f64(c0, BITS), code_to_f64(c1, BITS)};
-        FRAD_GPTR(v2d, dst)[p] = v;
+        FRAD_NT_STORE(v, FRAD_GPTR(v2d, dst) + p);
     };
     const long long step = (long long)bpf * blockDim.x;
     long long p = (long long)chunk * blockDim.x + threadIdx.x;
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(256) k_p4_unpack_12b(const unsigned char* __re
             val[i] = code_to_f64(c, BITS);
         }
 #pragma unroll
-        for (int i = 0; i < V / 2; ++i) { v2d v = {val[2 * i], val[2 * i + 1]}; FRAD_GPTR(v2d, dst + u * V)[i] = v; }
+        for (int i = 0; i < V / 2; ++i) { v2d v = {val[2 * i], val[2 * i + 1]}; FRAD_NT_STORE(v, FRAD_GPTR(v2d, dst + u * V) + i); }
     };
     const long long step = (long long)bpf * blockDim.x;
     long long u = (long long)chunk * blockDim.x + threadIdx.x;
@@ -821,7 +821,7 @@ __device__ FRAD_NOINLINE void store_pcm_f64(int smem_off, double* __restrict__ o
                 if (++c == C) { c = 0; ++n; }
                 const double v1 = xslot<double, SH>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n);
                 v2d v = {v0, v1};
-                FRAD_GPTR(v2d, dst)[p] = v;
+                FRAD_NT_STORE(v, FRAD_GPTR(v2d, dst) + p);
             }
         } else {
             for (int e = threadIdx.x; e < NC; e += blockDim.x) {
@@ -1012,7 +1012,7 @@ __device__ FRAD_NOINLINE void store_pcm_group(int smem_off, double* __restrict__
         for (int q = threadIdx.x; q < N * half; q += blockDim.x) {
             const int n = q / half, j = (q - n * half) * 2, m = makhoul(n, N);
             v2d v = {xslot<double, SH>(smem, j, slots, m), xslot<double, SH>(smem, j + 1, slots, m)};
-            *FRAD_GPTR(v2d, dst + (long long)n * C + c0 + j) = v;
+            FRAD_NT_STORE(v, FRAD_GPTR(v2d, dst + (long long)n * C + c0 + j));
         }
         return;
     }

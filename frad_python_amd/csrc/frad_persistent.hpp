@@ -703,14 +703,14 @@ __device__ FRAD_NOINLINE void store_frame_rows(int data_off, double* __restrict_
         for (int i = 0; i < N / uth; ++i) {
             const int n = utid + i * uth;
             v2d v = {sample(0, n), sample(1, n)};
-            FRAD_GPTR(v2d, dstf)[n] = v;
+            FRAD_NT_STORE(v, FRAD_GPTR(v2d, dstf) + n);
         }
     } else {
 #pragma unroll 8
         for (int i = 0; i < N / 2 / uth; ++i) {
             const int p = utid + i * uth;
             v2d v = {sample(0, 2 * p), sample(0, 2 * p + 1)};
-            FRAD_GPTR(v2d, dstf)[p] = v;
+            FRAD_NT_STORE(v, FRAD_GPTR(v2d, dstf) + p);
         }
     }
 }

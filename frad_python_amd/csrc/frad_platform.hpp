@@ -25,4 +25,12 @@
 // i.e. every global load and store in flight, which is exactly what a pipelined kernel must not do
 #define FRAD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
+// streaming (nontemporal) 16-byte accesses for data touched once; plain accesses under the emulator
+#ifdef FRAD_HOST_EMULATION
+#define FRAD_NT_LOAD(p) (*(p))
+#define FRAD_NT_STORE(v, p) (*(p) = (v))
+#else
+#define FRAD_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define FRAD_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
 #include <stdint.h>

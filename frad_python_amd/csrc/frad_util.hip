@@ -12,10 +12,10 @@ __global__ void __launch_bounds__(256) k_bench_copy(const v4u* __restrict__ src,
     for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
         const long long i = t * 1024 + threadIdx.x;
         if (i + 768 < n16) {
-            const v4u a = __builtin_nontemporal_load(FRAD_GCPTR(v4u, src) + i), b = __builtin_nontemporal_load(FRAD_GCPTR(v4u, src) + i + 256),
-                      c = __builtin_nontemporal_load(FRAD_GCPTR(v4u, src) + i + 512), d = __builtin_nontemporal_load(FRAD_GCPTR(v4u, src) + i + 768);
-            __builtin_nontemporal_store(a, FRAD_GPTR(v4u, dst) + i); __builtin_nontemporal_store(b, FRAD_GPTR(v4u, dst) + i + 256);
-            __builtin_nontemporal_store(c, FRAD_GPTR(v4u, dst) + i + 512); __builtin_nontemporal_store(d, FRAD_GPTR(v4u, dst) + i + 768);
+            const v4u a = FRAD_NT_LOAD(FRAD_GCPTR(v4u, src) + i), b = FRAD_NT_LOAD(FRAD_GCPTR(v4u, src) + i + 256),
+                      c = FRAD_NT_LOAD(FRAD_GCPTR(v4u, src) + i + 512), d = FRAD_NT_LOAD(FRAD_GCPTR(v4u, src) + i + 768);
+            FRAD_NT_STORE(a, FRAD_GPTR(v4u, dst) + i); FRAD_NT_STORE(b, FRAD_GPTR(v4u, dst) + i + 256);
+            FRAD_NT_STORE(c, FRAD_GPTR(v4u, dst) + i + 512); FRAD_NT_STORE(d, FRAD_GPTR(v4u, dst) + i + 768);
         } else {
             for (long long j = i; j < n16 && j < (t + 1) * 1024; j += 256) FRAD_GPTR(v4u, dst)[j] = FRAD_GCPTR(v4u, src)[j];
         }

@@ -491,7 +491,8 @@ k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         team_sync<64>();
         FRAD_STAMP(3);
         FRAD_FENCE();
-        dma_in(next < ue ? next : u);                          // raw landing zone is free from here on (no branch: the last unit re-reads itself)
+        dma_in(next < ue ? next : ub);                         // raw landing zone is free from here on (no branch; a wave's last DMA re-reads the
+                                                               //  block's first unit, which its six neighbours hit in L2 -- never consumed)
         FRAD_FENCE();
         // ---- pair-step tables of the first group, then pass 2 proper -----------------------------------
         // group g (processed from NG - 1 down to 0) holds jobs t and 15 - t for t in [g JPG / 2, (g + 1) JPG / 2)
