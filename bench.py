@@ -7,8 +7,9 @@ Workload : --workload cfg2 (default) = configs[1]: 10 min of 48 kHz stereo s16le
            MI355X.  Synthetic "signal A" (harmonic mix + -60 dBFS noise), generated on the GPU.
            --workload cfg3 = configs[2]: 4096 x 1 s stereo clips (23 full frames + an 896-sample tail each), whole clips
            sharded over the ranks (contiguous ranges, parallel.shard_range): strong scaling, still no collective.
-Step     : one pass of the hot path over the whole workload: analogue (encode) of every frame, the batch overflow test,
-           then digital (decode) of every payload; inputs are resident in HBM when the clock starts.
+Step     : one pass of the hot path over the whole workload: analogue (encode) of every frame with the reference's overflow
+           test in the same pass (frad_p0_analogue_checked), then digital (decode) of every payload; inputs are resident in
+           HBM when the clock starts.
 N > 1    : one process per GPU.  Started by the driver (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE) or,
            when `--gpus N` is given without that environment, by this script: the parent starts N children BEFORE it
            touches the GPU itself and never re-executes a process that has.  cfg2: every rank owns one clip (weak
@@ -248,8 +249,7 @@ def main():
             am = d["absmax_all"][self.n_full:]
             src = d["tails"] if self.gather else d["clips"][0, self.full_per_clip * FSIZE:]
             core.analogue_batch(0, src, "s16le", self.n_tail, self.tail, CHANNELS, BITS, False, check_overflow=False,
-                                out=d["pay_t"], absmax=am)
-            core.overflow_scan(am, BITS, self.over)
+                                out=d["pay_t"], absmax=am, overflow_flag=self.over)
             core.digital_batch(0, d["pay_t"], self.n_tail, self.tail, CHANNELS, BITS, False, out=d["out_t"])
 
         def encode(self, ev=None):
@@ -261,8 +261,10 @@ def main():
             else:
                 src = d["clips"]
             if ev: ev[0].record()
+            # (the reference's per-frame overflow test, profile0.py:24-26, rides along: frad_p0_analogue_checked sets the
+            #  sticky device flag; the host reads it once, after the timed region)
             core.analogue_batch(0, src, "s16le", self.n_full, FSIZE, CHANNELS, BITS, False, check_overflow=False,
-                                out=d["pay"], absmax=d["absmax_all"][:self.n_full])
+                                out=d["pay"], absmax=d["absmax_all"][:self.n_full], overflow_flag=self.over)
             if ev: ev[1].record()
             if self.tail:
                 if self.gather:
@@ -277,13 +279,8 @@ def main():
             core.digital_batch(0, d["pay"], self.n_full, FSIZE, CHANNELS, BITS, False, out=d["out"])
             if ev: ev[1].record()
 
-        def overflow_check(self):
-            """The reference's per-frame overflow test (profile0.py:24-26): evaluated on the device every step over all
-            frames (one launch, frad_p0_overflow_scan); the host reads the sticky flag once, after the timed region."""
-            core.overflow_scan(self.cur["absmax_all"][:self.n_full], BITS, self.over)
-
         def step(self, ev_e=None, ev_d=None):
-            self.encode(ev_e); self.overflow_check(); self.decode(ev_d)
+            self.encode(ev_e); self.decode(ev_d)
 
     wl = Workload(seed=1234 + rank)
 

@@ -27,6 +27,8 @@ SYMBOLS = {
     "frad_plan_clear": (None, []),
     "frad_p0_analogue": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_int32, c_int64, c_int32, c_uint32,
                                  c_void_p, c_int64, c_void_p, c_void_p]),
+    "frad_p0_analogue_checked": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_int32, c_int64, c_int32, c_uint32,
+                                         c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "frad_p0_overflow_scan": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "frad_p0_digital": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_uint32, c_void_p, c_void_p]),
     "frad_p4_analogue": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_int32, c_int64, c_int32, c_uint32,
@@ -79,6 +81,10 @@ class FradLib:
     def p0_analogue(self, pcm, dtype, n_frames, N, C, frame_stride, bits, flags, payload, payload_stride, absmax, stream=0):
         self._check(self.dll.frad_p0_analogue(pcm, dtype, n_frames, N, C, frame_stride, bits, flags, payload,
                                                payload_stride, absmax, stream))
+
+    def p0_analogue_checked(self, pcm, dtype, n_frames, N, C, frame_stride, bits, flags, payload, payload_stride, absmax, flag, stream=0):
+        self._check(self.dll.frad_p0_analogue_checked(pcm, dtype, n_frames, N, C, frame_stride, bits, flags, payload,
+                                                       payload_stride, absmax, flag, stream))
 
     def crc32_frames(self, data, stride, n_frames, nbytes, out, stream=0):
         self._check(self.dll.frad_crc32_frames(data, stride, n_frames, nbytes, out, stream))

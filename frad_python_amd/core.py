@@ -76,12 +76,13 @@ class EncodedBatch:
 def analogue_batch(profile: int, pcm: torch.Tensor, pcm_format: str, n_frames: int, N: int, C: int, bits: int,
                    little_endian: bool = False, *, frame_stride: int | None = None, raw_be_ints: bool = True,
                    check_overflow: bool = True, out: torch.Tensor | None = None,
-                   absmax: torch.Tensor | None = None) -> EncodedBatch:
+                   absmax: torch.Tensor | None = None, overflow_flag: torch.Tensor | None = None) -> EncodedBatch:
     """Profile 0 (DCT) or 4 (PCM) ``analogue`` over a batch of frames.
 
     ``pcm`` is the raw interleaved PCM (any tensor dtype; ``pcm_format`` names the element type as
     the reference's CLI does, e.g. ``s16le``), frame i starting ``frame_stride`` (default N)
-    sample-frames after frame i-1."""
+    sample-frames after frame i-1.  ``overflow_flag`` (profile 0, device int32 scalar): the batch form of the reference's
+    overflow test in the same pass -- set to 1 when a frame needs a deeper format, read it when the answer is needed."""
     _require_cuda(pcm, "pcm")
     if bits not in DEPTHS:
         bits = 16                                         # ref: profile0.py:15
@@ -100,8 +101,15 @@ def analogue_batch(profile: int, pcm: torch.Tensor, pcm_format: str, n_frames: i
     flags = (int(little_endian) * _lib.FRAD_LITTLE_ENDIAN) | (int(raw_be_ints) * _lib.FRAD_RAW_BE_INTS)
     fn = lib.p4_analogue if profile == 4 else lib.p0_analogue
     with torch.cuda.device(pcm.device):
-        fn(pcm.data_ptr(), code, n_frames, N, C, stride_frames, bits, flags, out.data_ptr(), out.stride(0),
-           absmax.data_ptr(), _stream_ptr())
+        if overflow_flag is not None and profile != 4:
+            _require_cuda(overflow_flag, "overflow_flag")
+            if overflow_flag.dtype != torch.int32:
+                raise TypeError("overflow_flag must be int32")
+            lib.p0_analogue_checked(pcm.data_ptr(), code, n_frames, N, C, stride_frames, bits, flags, out.data_ptr(), out.stride(0),
+                                    absmax.data_ptr(), overflow_flag.data_ptr(), _stream_ptr())
+        else:
+            fn(pcm.data_ptr(), code, n_frames, N, C, stride_frames, bits, flags, out.data_ptr(), out.stride(0),
+               absmax.data_ptr(), _stream_ptr())
     escalated = {}
     if check_overflow and n_frames:
         over = absmax > FLOAT_MAX[bits]                   # NaN compares False, as in the reference

@@ -211,6 +211,7 @@ Geom make_geom(long long n_frames, int N, int C, long long frame_stride, long lo
     g.n_frames = n_frames; g.frame_stride = frame_stride; g.payload_stride = payload_stride;
     g.N = N; g.C = C; g.bits = bits; g.le = (flags & FRAD_LITTLE_ENDIAN) ? 1 : 0; g.dtype = dtype;
     g.raw_be = (flags & FRAD_RAW_BE_INTS) ? 1 : 0; g.fpb = 1; g.n_valid = N; g.cg = C; g.in_mode = 0; g.cc_fast = 0;
+    g.ovf_flag = nullptr; g.ovf_limit = 0.0;
     return g;
 }
 
@@ -337,11 +338,15 @@ int frad_p4_digital(const void* payload, int64_t payload_stride, int64_t n_frame
     return FRAD_OK;
 }
 
+static double storage_float_max(int bits) {                  // FLOAT_DR, profile0.py:6-13
+    return bits <= 16 ? 65504.0 : bits <= 32 ? 3.4028234663852886e38 : 1.7976931348623157e308;
+}
+
 int frad_p0_overflow_scan(const double* absmax, int64_t n_frames, int32_t bits, int32_t* flag, void* stream) {
     if (n_frames < 0 || !valid_bits(bits)) return FRAD_E_INVALID;
     if (n_frames == 0) return FRAD_OK;
     if (!absmax || !flag) return FRAD_E_INVALID;
-    const double lim = bits <= 16 ? 65504.0 : bits <= 32 ? 3.4028234663852886e38 : 1.7976931348623157e308;   // FLOAT_DR, profile0.py:6-13
+    const double lim = storage_float_max(bits);
     long long blocks = (n_frames + 1023) / 1024;
     if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(k_overflow_scan<0>, dim3((unsigned)blocks), dim3(1024), 0, static_cast<hipStream_t>(stream), absmax, (long long)n_frames, lim, flag);
@@ -351,7 +356,14 @@ int frad_p0_overflow_scan(const double* absmax, int64_t n_frames, int32_t bits, 
 
 int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C, int64_t frame_stride,
                      int32_t bits, uint32_t flags, void* payload, int64_t payload_stride, double* absmax, void* stream) {
+    return frad_p0_analogue_checked(pcm, pcm_dtype, n_frames, N, C, frame_stride, bits, flags, payload, payload_stride, absmax, nullptr, stream);
+}
+
+int frad_p0_analogue_checked(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C, int64_t frame_stride,
+                             int32_t bits, uint32_t flags, void* payload, int64_t payload_stride, double* absmax,
+                             int32_t* overflow_flag, void* stream) {
     int rc = check_common(pcm, payload, n_frames, N, C, bits);
+    if (rc == FRAD_OK && overflow_flag != nullptr && absmax == nullptr && n_frames > 0) return FRAD_E_INVALID;      // the test reads the per-frame maxima
     if (rc != FRAD_OK) return rc;
     if (!valid_dtype(pcm_dtype)) return FRAD_E_INVALID;
     if (n_frames == 0) return FRAD_OK;
@@ -364,7 +376,13 @@ int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
     const int ao = (aligned16(payload) && payload_stride % 16 == 0) ? 1 : 0;
     const unsigned char* in = static_cast<const unsigned char*>(pcm);
     unsigned char* out = static_cast<unsigned char*>(payload);
-    if (launch_p0_fwd_wave(lg, s, in, out, absmax, g, ai, ao, unit_neg)) { HIPCHK(hipGetLastError()); return FRAD_OK; }
+    {
+        Geom gw = g;                                          // the wave kernels apply the overflow test themselves
+        gw.ovf_flag = overflow_flag; gw.ovf_limit = storage_float_max(bits);
+        if (launch_p0_fwd_wave(lg, s, in, out, absmax, gw, ai, ao, unit_neg)) { HIPCHK(hipGetLastError()); return FRAD_OK; }
+    }
+    // every other kernel: the batch form of the test as a second launch on the same stream
+    const int rc_all = [&]() -> int {
     const FastCfg c = fast_cfg(N, C, f32);
     if (c.ok) {
         Tables tb; rc = get_tables(c.log2m, f32, tb);
@@ -407,6 +425,10 @@ int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
 #undef FRAD_DIR
     }
     HIPCHK(hipGetLastError());
+    return FRAD_OK;
+    }();
+    if (rc_all != FRAD_OK) return rc_all;
+    if (overflow_flag != nullptr) return frad_p0_overflow_scan(absmax, n_frames, bits, overflow_flag, stream);
     return FRAD_OK;
 }
 

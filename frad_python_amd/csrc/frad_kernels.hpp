@@ -37,6 +37,8 @@ struct Geom {
     int in_mode;                // FFT kernels, PCM side: 0 = per element, 1/2/3 = quad stage-in (row bytes
                                 // divide 16 / equal 8 / multiple of 16), see stage_in_quads
     int cc_fast;                // FFT kernels, payload side: 1 or 2 = pairwise 16-byte LDS path for C = 1 / 2
+    int* ovf_flag;              // frad_p0_analogue_checked: set to 1 when a frame's |X| max exceeds ovf_limit (else untouched); may be null
+    double ovf_limit;
 };
 
 __device__ __forceinline__ bool dtype_is_f32_class(int code) { return (code >> 3) == 2 && ((code >> 1) & 3) <= 2; }

@@ -156,6 +156,7 @@ int launch_p0_inv_wave(hipStream_t s, const unsigned char* pay, double* out, con
     const int grid = (int)(nb < cap ? nb : cap);
     Geom gg = g;
     gg.cg = wave_stagger();
+    { static const int plain = [] { const char* e = tune("FRAD_TUNE_WAVE_PLAIN_LOADS"); return e ? atoi(e) : 0; }(); gg.fpb = plain; }
     if (g.C == 2) go_inv_wave_bits<2>(blob, grid, s, pay, out, gg);
     else go_inv_wave_bits<1>(blob, grid, s, pay, out, gg);
     return 1;

@@ -629,11 +629,18 @@ k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
             if (absmax != nullptr) {
                 if constexpr (CC == 2) {
                     mx = wave_max_u64(mx);
-                    if (lane == 0) *FRAD_GPTR(u64, absmax + f) = mx;
+                    if (lane == 0) {
+                        *FRAD_GPTR(u64, absmax + f) = mx;
+                        if (g.ovf_flag != nullptr && u2d(mx) > g.ovf_limit) atomicOr(g.ovf_flag, 1);      // (NaN compares false, as in the reference)
+                    }
                 } else {
                     u64 m0, m1;
                     half_wave_max_u64(mx, m0, m1);
-                    if (l == 0 && live) *FRAD_GPTR(u64, absmax + f) = h ? m1 : m0;
+                    if (l == 0 && live) {
+                        const u64 mm = h ? m1 : m0;
+                        *FRAD_GPTR(u64, absmax + f) = mm;
+                        if (g.ovf_flag != nullptr && u2d(mm) > g.ovf_limit) atomicOr(g.ovf_flag, 1);
+                    }
                 }
             }
         }
@@ -731,6 +738,11 @@ k_p0_inv_wave(const unsigned char* __restrict__ payload, double* __restrict__ ou
             else if constexpr (BITS == 32) return *FRAD_GCPTR(uint32_t, p);
             else return *FRAD_GCPTR(u64, p);
 #else                                                          // read once: nontemporal (keeps the streams out of each other's way in L2 / MALL)
+            if (g.fpb) {
+                if constexpr (BITS == 16) return *FRAD_GCPTR(unsigned short, p);
+                else if constexpr (BITS == 32) return *FRAD_GCPTR(uint32_t, p);
+                else return *FRAD_GCPTR(u64, p);
+            }
             if constexpr (BITS == 16) return __builtin_nontemporal_load(FRAD_GCPTR(unsigned short, p));
             else if constexpr (BITS == 32) return __builtin_nontemporal_load(FRAD_GCPTR(uint32_t, p));
             else return __builtin_nontemporal_load(FRAD_GCPTR(u64, p));

@@ -89,6 +89,13 @@ int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
  * greater than the largest finite value of the `bits` storage float (NaN never is, like numpy's
  * comparison).  `flag` is a device int32 the caller zeroes once and reads when it needs the answer
  * (sticky across calls), so a steady stream of batches needs no host round trip per batch.        */
+/* frad_p0_analogue with the reference's per-frame overflow test (profile0.py:24-26) applied in the same pass:
+ * *overflow_flag is set to 1 when any frame's max|X| exceeds the storage float's largest finite value (NaN does not
+ * count, as in the reference), and left alone otherwise.  The N = 2048 wave kernels test as they go; every other
+ * geometry runs frad_p0_overflow_scan behind the transform on the same stream.  `absmax` is required.              */
+int frad_p0_analogue_checked(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C,
+                             int64_t frame_stride, int32_t bits, uint32_t flags, void* payload, int64_t payload_stride,
+                             double* absmax, int32_t* overflow_flag, void* stream);
 int frad_p0_overflow_scan(const double* absmax, int64_t n_frames, int32_t bits, int32_t* flag, void* stream);
 
 /* frad_p0_digital == fourier.profile0.digital (profile0.py:46-69): unpack, NaN/Inf -> 0, inverse

@@ -108,3 +108,27 @@ def test_one_escalating_frame_among_many(fmt, N, C):
         else:
             d1, d2 = fo.decode_stream(out), fo.decode_stream(ref)
             assert np.max(np.abs(d1 - d2)) <= 1e-9 * max(1.0, np.max(np.abs(d2))), prof
+
+
+def test_checked_analogue_sets_the_sticky_overflow_flag():
+    """frad_p0_analogue_checked == frad_p0_analogue + frad_p0_overflow_scan (profile0.py:24-26 over a batch), for the
+    wave kernels (test fused into the transform) and for the other geometries (scan launched behind it)."""
+    import torch
+    from frad_python_amd import core
+    rng = np.random.default_rng(3)
+    for (N, C, fmt) in ((2048, 2, "f64le"), (2048, 1, "f64le"), (1024, 2, "f64le"), (896, 2, "f64le")):
+        F = 9
+        x = rng.uniform(-1, 1, (F * N, C))
+        for hot in (False, True):
+            if hot:
+                x[4 * N + 7, 0] = 3.0e38                      # frame 4 overflows float16 storage
+            raw = _dev(np.ascontiguousarray(x, "<f8").view(np.uint8).reshape(-1))
+            flag = torch.zeros((), dtype=torch.int32, device="cuda:0")
+            a = core.analogue_batch(0, raw, fmt, F, N, C, 16, False, check_overflow=False, overflow_flag=flag)
+            b = core.analogue_batch(0, raw, fmt, F, N, C, 16, False, check_overflow=False)
+            assert torch.equal(a.payload, b.payload) and torch.equal(a.absmax, b.absmax)
+            assert int(flag.item()) == int(hot), (N, C, hot)
+            assert bool((a.absmax > 65504).any()) == hot
+        flag = torch.ones((), dtype=torch.int32, device="cuda:0")           # sticky: a clean batch leaves it set
+        core.analogue_batch(0, _dev(np.zeros(F * N * C, "<f8").view(np.uint8)), fmt, F, N, C, 16, False, check_overflow=False, overflow_flag=flag)
+        assert int(flag.item()) == 1
