@@ -39,6 +39,10 @@ SYMBOLS = {
     "frad_p1_digital": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "frad_crc32_frames": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "frad_p1_overlap_add": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "frad_p1_golomb_bound": (c_size_t, [c_int32, c_int32]),
+    "frad_p1_golomb_encode": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
+    "frad_rows_compact": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "frad_p1_golomb_decode": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "frad_bench_copy": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
@@ -108,6 +112,18 @@ class FradLib:
 
     def p1_digital(self, q, tq, n_frames, N, C, bits, srate, out, stream=0):
         self._check(self.dll.frad_p1_digital(q, tq, n_frames, N, C, bits, srate, out, stream))
+
+    def p1_golomb_bound(self, N, C):
+        return int(self.dll.frad_p1_golomb_bound(N, C))
+
+    def p1_golomb_encode(self, q, tq, n_frames, N, C, bodies, body_stride, body_bytes, stream=0):
+        self._check(self.dll.frad_p1_golomb_encode(q, tq, n_frames, N, C, bodies, body_stride, body_bytes, stream))
+
+    def rows_compact(self, rows, row_stride, row_bytes, n_rows, out, offsets, stream=0):
+        self._check(self.dll.frad_rows_compact(rows, row_stride, row_bytes, n_rows, out, offsets, stream))
+
+    def p1_golomb_decode(self, bodies, offsets, n_frames, N, C, q, tq, status, stream=0):
+        self._check(self.dll.frad_p1_golomb_decode(bodies, offsets, n_frames, N, C, q, tq, status, stream))
 
     def bench_copy(self, src, dst, nbytes, stream=0):
         self._check(self.dll.frad_bench_copy(src, dst, nbytes, stream))

@@ -1,0 +1,322 @@
+// frad_golomb.hip -- profile 1's Exp-Golomb-Rice stage on the device.
+//
+// Reference: fourier/tools/p1tools.py:46-60 (exp_golomb_rice_encode), :62-74 (exp_golomb_rice_decode) and the frame
+// body layout of fourier/profile1.py:43-45 / :59-64:
+//
+//     body = struct.pack('>I', len(thres_gol)) + thres_gol + freqs_gol        (then deflated on the host)
+//     *_gol = byte k, then per value v the zig-zag code z (v > 0: 2v - 1, else -2v) written as m zeros followed by
+//             the (m + k + 1)-bit binary of z + 2^k, MSB first, zero-padded to a byte;  k = ceil(log2(max |v|))
+//
+// With k taken from the maximum, z + 2^k < 2^(k+2): every value costs k + 1 or k + 3 bits, so a frame's worst case is
+// known up front (frad_p1_golomb_bound) and the coder needs no second look at the data.
+//
+//   k_gol_encode   one 256-thread block per frame: |max| reduction -> k, per-thread code lengths of 16 consecutive
+//                  values -> block scan -> bit offsets -> codes OR-ed into an LDS word buffer -> big-endian words out.
+//                  Frames longer than a tile (4096 values) carry the partial last word into the next tile.
+//   k_rows_scan / k_rows_gather   exclusive scan of the body lengths and a gather into one contiguous buffer, so
+//                  that a batch goes back to the host (zlib) as ONE copy of exactly the bytes it needs.
+//   k_gol_decode   one LANE per (frame, stream): the code boundaries of a prefix code are a sequential dependency, so
+//                  the parallelism is across frames and the two streams of a frame; 64-bit window reader, values
+//                  written as they fall out.  Semantics of the reference decoder incl. its end conditions (a run of
+//                  zero bits ends the stream; a code cut short by the end of the buffer is read from the bits there).
+#include "frad_common.hpp"
+#include "../../include/frad_hip.h"
+
+namespace frad {
+namespace {
+
+constexpr int GT = 256;                    // threads per encode block
+constexpr int GV = 16;                     // consecutive values per thread and tile
+constexpr int GTILE = GT * GV;             // values per tile
+constexpr int GWORDS = (GTILE * 35 + 31) / 32 + 4;     // 32-bit words a tile can fill (<= 35 bits per value) + carry
+constexpr int GOL_LDS = GWORDS * 4 + GT * 8;
+
+__device__ __forceinline__ int bitlen64(u64 v) { return v ? 64 - __builtin_clzll(v) : 0; }
+__device__ __forceinline__ u64 zigzag(int32_t v) { return v > 0 ? 2ull * (u64)v - 1ull : 2ull * (u64)(-(long long)v); }
+// k = ceil(log2(dmax)) for dmax >= 1 (numpy evaluates it in float64, exact for |v| < 2^53), 0 for dmax = 0
+__device__ __forceinline__ int rice_k(u64 dmax) { return dmax <= 1 ? 0 : bitlen64(dmax - 1); }
+
+struct BitSink {                           // the body as ONE bit sequence; LDS words hold bits [base, base + 32 * GWORDS)
+    int* words;                            // LDS, MSB-first inside a word
+    unsigned char* out;                    // the frame's row (4-byte aligned)
+    long long base;                        // bit position of words[0], a multiple of 32
+};
+
+// OR `nbits` (<= 64) bits of `code` into the sink at absolute bit position `pos`
+__device__ __forceinline__ void sink_put(const BitSink& s, long long pos, u64 code, int nbits) {
+    int rel = (int)(pos - s.base);
+    while (nbits > 0) {
+        const int w = rel >> 5, off = rel & 31, room = 32 - off;
+        const int take = nbits < room ? nbits : room;
+        const uint32_t piece = (uint32_t)((code >> (nbits - take)) & ((take == 32) ? 0xffffffffull : ((1ull << take) - 1ull)));
+        atomicOr(&s.words[w], (int)(piece << (room - take)));
+        rel += take; nbits -= take;
+    }
+}
+// store the complete words below `pos`, keep the partial one as word 0 of the next stretch; block-wide
+__device__ __forceinline__ void sink_flush(BitSink& s, long long pos, bool final_) {
+    __syncthreads();
+    const int full = (int)((pos - s.base) >> 5), part = (int)((pos - s.base) & 31);
+    const int n = final_ && part ? full + 1 : full;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s.out + (s.base >> 3));
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = bswap32((uint32_t)s.words[i]);
+    const int carry = part ? s.words[full] : 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < GWORDS; i += blockDim.x) s.words[i] = (i == 0) ? carry : 0;
+    s.base += (long long)full * 32;
+    __syncthreads();
+}
+
+// block-wide inclusive scan of one int per thread (GT threads); returns this thread's inclusive sum, *total = block sum
+__device__ __forceinline__ long long block_scan(long long v, long long* tmp, long long* total) {
+    tmp[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < GT; off <<= 1) {
+        const long long add = threadIdx.x >= (unsigned)off ? tmp[threadIdx.x - off] : 0;
+        __syncthreads();
+        tmp[threadIdx.x] += add;
+        __syncthreads();
+    }
+    const long long r = tmp[threadIdx.x];
+    *total = tmp[GT - 1];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ u64 block_max(u64 v, u64* tmp) {
+    v = wave_max_u64(v);
+    if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    u64 r = 0;
+    for (int i = 0; i < GT / 64; ++i) r = tmp[i] > r ? tmp[i] : r;
+    __syncthreads();
+    return r;
+}
+
+// one stream (n values at `data`) appended at bit position `pos` (byte aligned): k byte + codes + zero padding
+__device__ long long encode_stream(BitSink& s, long long pos, const int32_t* __restrict__ data, long long n, long long* tmp) {
+    u64 dmax = 0;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) { const long long v = data[i]; const u64 a = (u64)(v < 0 ? -v : v); dmax = a > dmax ? a : dmax; }
+    dmax = block_max(dmax, reinterpret_cast<u64*>(tmp));
+    const int k = rice_k(dmax);
+    if (threadIdx.x == 0) sink_put(s, pos, (u64)k, 8);
+    pos += 8;
+    for (long long t0 = 0; t0 < n; t0 += GTILE) {
+        const long long j0 = t0 + (long long)threadIdx.x * GV;
+        u64 code[GV]; int len[GV]; long long mine = 0;
+#pragma unroll
+        for (int i = 0; i < GV; ++i) {
+            len[i] = 0; code[i] = 0;
+            if (j0 + i < n) {
+                code[i] = zigzag(data[j0 + i]) + (1ull << k);
+                const int L = bitlen64(code[i]);
+                len[i] = 2 * L - (k + 1);                      // m = L - (k + 1) zeros, then the L-bit number
+                mine += len[i];
+            }
+        }
+        long long total;
+        long long at = pos + block_scan(mine, tmp, &total) - mine;
+#pragma unroll
+        for (int i = 0; i < GV; ++i) if (len[i]) { sink_put(s, at, code[i], len[i]); at += len[i]; }
+        pos += total;
+        sink_flush(s, pos, false);
+    }
+    return (pos + 7) & ~7LL;                                   // bitstr2bytes pads with zeros
+}
+
+__global__ void __launch_bounds__(GT) k_gol_encode(const int32_t* __restrict__ q, const int32_t* __restrict__ tq, long long nq, long long ntq,
+                                                   unsigned char* __restrict__ body, long long stride, long long* __restrict__ nbytes) {
+    FRAD_DYN_SMEM(smem);                                      // GOL_LDS bytes: the word buffer, then the scan scratch
+    int* words = reinterpret_cast<int*>(smem);
+    long long* tmp = reinterpret_cast<long long*>(smem + GWORDS * 4);
+    const long long f = blockIdx.x;
+    BitSink s{words, body + f * stride, 0};
+    for (int i = threadIdx.x; i < GWORDS; i += blockDim.x) words[i] = 0;
+    __syncthreads();
+    // '>I' len(thres_gol) is only known once that stream is coded: it goes first, so code the thresholds from bit 32
+    // on and patch the length in afterwards (the words of the first tile are still in LDS or already stored)
+    const long long end_t = encode_stream(s, 32, tq + f * ntq, ntq, tmp);
+    const long long end_q = encode_stream(s, end_t, q + f * nq, nq, tmp);
+    sink_flush(s, end_q, true);
+    if (threadIdx.x == 0) {
+        const uint32_t tlen = (uint32_t)((end_t - 32) >> 3);
+        *reinterpret_cast<uint32_t*>(s.out) = bswap32(tlen);
+        nbytes[f] = end_q >> 3;
+    }
+}
+
+// offsets[0] = 0, offsets[i + 1] = offsets[i] + nbytes[i]; one block
+__global__ void __launch_bounds__(GT) k_rows_scan(const long long* __restrict__ nbytes, long long n, long long* __restrict__ offsets) {
+    FRAD_DYN_SMEM(smem);
+    long long* tmp = reinterpret_cast<long long*>(smem);
+    long long carry = 0;
+    if (threadIdx.x == 0) offsets[0] = 0;
+    for (long long i0 = 0; i0 < n; i0 += GT) {
+        const long long i = i0 + threadIdx.x;
+        const long long v = i < n ? nbytes[i] : 0;
+        long long total;
+        const long long inc = block_scan(v, tmp, &total);
+        if (i < n) offsets[i + 1] = carry + inc;
+        carry += total;
+    }
+}
+__global__ void __launch_bounds__(GT) k_rows_gather(const unsigned char* __restrict__ rows, long long stride, const long long* __restrict__ offsets,
+                                                    unsigned char* __restrict__ out) {
+    const long long f = blockIdx.x, a = offsets[f], n = offsets[f + 1] - a;
+    const unsigned char* src = rows + f * stride;
+    unsigned char* dst = out + a;
+    // rows are 4-byte aligned, the packed position is not: align the destination, then copy words through a funnel shift
+    long long i = threadIdx.x;
+    const int head = (int)((4 - (reinterpret_cast<uintptr_t>(dst) & 3)) & 3);
+    if (i < head && i < n) dst[i] = src[i];
+    const long long words = n > head ? (n - head) >> 2 : 0;
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + head);
+    const int sh = head * 8;
+    for (long long w = threadIdx.x; w < words; w += blockDim.x) {
+        const uint32_t lo = s32[w], hi = sh ? s32[w + 1] : 0;  // s32[w + 1] stays inside the row: stride covers the bound + 4
+        d32[w] = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+    }
+    for (long long b = head + words * 4 + threadIdx.x; b < n; b += blockDim.x) dst[b] = src[b];
+}
+
+// ---- decode --------------------------------------------------------------------------------------------------------
+struct BitReader {                                            // MSB-first reader over whole bytes, 64-bit window
+    const unsigned char* p; long long nbytes, next;           // next: first byte not yet in the window
+    u64 win; int have;                                        // the top `have` bits of `win` are the next unread bits
+    __device__ __forceinline__ void refill() {
+        while (have <= 56 && next < nbytes) { win |= (u64)p[next++] << (56 - have); have += 8; }
+    }
+    __device__ __forceinline__ long long left() const { return (long long)have + 8 * (nbytes - next); }
+    __device__ __forceinline__ void drop(int n) { win = n >= 64 ? 0 : win << n; have -= n; }
+};
+
+__device__ __forceinline__ int32_t sat32(long long v) { return v > 2147483647LL ? 2147483647 : v < -2147483648LL ? (int32_t)(-2147483647 - 1) : (int32_t)v; }
+
+// decode one stream into out[0 .. cap), zero-fill what the stream does not cover
+__device__ void decode_stream(const unsigned char* p, long long len, int32_t* __restrict__ out, long long cap) {
+    long long n_out = 0;
+    if (len >= 1) {
+        const int k = p[0];
+        BitReader r{p + 1, len - 1, 0, 0ull, 0};
+        while (n_out < cap) {
+            // m = index of the first '1' (p1tools.py:68); none left: stop
+            long long m = 0; bool found = false;
+            for (;;) {
+                r.refill();
+                if (r.have == 0) break;
+                if (r.win == 0) { m += r.have; r.have = 0; continue; }
+                const int z = __builtin_clzll(r.win);           // < have: only the top `have` bits can be set
+                m += z; r.drop(z); found = true; break;
+            }
+            if (!found) break;
+            // the codeword is data[:2m + k + 1]: the m zeros just skipped and m + k + 1 more bits -- fewer at the end of
+            // the buffer, where Python's slice is simply shorter
+            long long want = m + (long long)k + 1;
+            const long long left = r.left();
+            if (want > left) want = left;
+            u64 val = 0; bool big = false;
+            while (want > 0) {
+                r.refill();
+                int take = want > 32 ? 32 : (int)want;
+                if (take > r.have) take = r.have;
+                if (val >> (64 - take)) big = true;
+                val = (val << take) | (r.win >> (64 - take));
+                r.drop(take); want -= take;
+            }
+            // n = int(codeword, 2) - 2^k; value = (n + 1) >> 1 if n is odd else -(n >> 1)   (Python integers)
+            long long v;
+            if (big || k >= 62 || val >= (1ull << 62)) {
+                // beyond anything an int32 quantiser emits (a corrupt stream): keep the sign rule, saturate the size
+                const bool n_neg = !big && (k >= 64 || (k >= 62 && val < (1ull << k)));
+                const bool odd = ((val & 1ull) != 0) != (k == 0);
+                v = (odd != n_neg) ? 0x7fffffffffffLL : -0x7fffffffffffLL;
+            } else {
+                const long long n = (long long)val - (1LL << k);
+                v = (n & 1) ? (n + 1) >> 1 : -(n >> 1);
+            }
+            out[n_out++] = sat32(v);
+        }
+    }
+    for (; n_out < cap; ++n_out) out[n_out] = 0;
+}
+
+__global__ void __launch_bounds__(64) k_gol_decode(const unsigned char* __restrict__ bodies, const long long* __restrict__ offsets, long long n_frames,
+                                                   long long nq, long long ntq, int32_t* __restrict__ q, int32_t* __restrict__ tq,
+                                                   int32_t* __restrict__ status) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long f = t >> 1; const int which = (int)(t & 1);             // 0: thresholds, 1: coefficients
+    if (f >= n_frames) return;
+    const unsigned char* b = bodies + offsets[f];
+    const long long len = offsets[f + 1] - offsets[f];
+    int32_t* dst = which ? q + f * nq : tq + f * ntq;
+    const long long cap = which ? nq : ntq;
+    if (len < 4) {                                            // no length word: nothing decodable (the host treats it as broken)
+        for (long long i = 0; i < cap; ++i) dst[i] = 0;
+        if (which == 0 && status) status[f] = 1;
+        return;
+    }
+    long long tlen = ((long long)b[0] << 24) | ((long long)b[1] << 16) | ((long long)b[2] << 8) | (long long)b[3];
+    if (tlen > len - 4) tlen = len - 4;                       // frad[:thresbytes] past the end: Python slicing clamps
+    if (which == 0) { decode_stream(b + 4, tlen, dst, cap); if (status) status[f] = 0; }
+    else decode_stream(b + 4 + tlen, len - 4 - tlen, dst, cap);
+}
+
+thread_local int g_gol_hip = 0;
+#define GOLCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_gol_hip = (int)e_; return FRAD_E_HIP; } } while (0)
+
+}  // namespace
+int golomb_last_hip_error() { return g_gol_hip; }
+}  // namespace frad
+
+using namespace frad;
+
+extern "C" {
+
+size_t frad_p1_golomb_bound(int32_t N, int32_t C) {
+    if (N < 1 || C < 1) return 0;
+    const size_t nq = (size_t)N * (size_t)C, nt = 27 * (size_t)C;
+    const size_t bytes = 4 + (1 + (nt * 35 + 7) / 8) + (1 + (nq * 35 + 7) / 8);
+    return (bytes + 8 + 15) / 16 * 16;                        // + one word of slack for the gather's funnel read
+}
+
+int frad_p1_golomb_encode(const int32_t* q, const int32_t* tq, int64_t n_frames, int32_t N, int32_t C,
+                          void* bodies, int64_t body_stride, int64_t* body_bytes, void* stream) {
+    if (n_frames < 0 || N < 1 || C < 1 || C > 256) return FRAD_E_INVALID;
+    if (n_frames == 0) return FRAD_OK;
+    if (!q || !tq || !bodies || !body_bytes) return FRAD_E_INVALID;
+    if (body_stride < (int64_t)frad_p1_golomb_bound(N, C) || (body_stride & 3) || (reinterpret_cast<uintptr_t>(bodies) & 3)) return FRAD_E_INVALID;
+    if (n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_gol_encode, dim3((unsigned)n_frames), dim3(GT), GOL_LDS, static_cast<hipStream_t>(stream), q, tq, (long long)N * C, 27LL * C,
+                       static_cast<unsigned char*>(bodies), (long long)body_stride, reinterpret_cast<long long*>(body_bytes));
+    GOLCHK(hipGetLastError());
+    return FRAD_OK;
+}
+
+int frad_rows_compact(const void* rows, int64_t row_stride, const int64_t* row_bytes, int64_t n_rows, void* out, int64_t* offsets, void* stream) {
+    if (n_rows < 0 || row_stride < 0) return FRAD_E_INVALID;
+    if (!offsets) return FRAD_E_INVALID;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n_rows > 0 && (!rows || !row_bytes || (reinterpret_cast<uintptr_t>(rows) & 3) || (row_stride & 3))) return FRAD_E_INVALID;
+    if (n_rows > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(GT), GT * 8, s, reinterpret_cast<const long long*>(row_bytes), (long long)n_rows, reinterpret_cast<long long*>(offsets));
+    if (n_rows > 0 && out)
+        hipLaunchKernelGGL(k_rows_gather, dim3((unsigned)n_rows), dim3(GT), 0, s, static_cast<const unsigned char*>(rows), (long long)row_stride,
+                           reinterpret_cast<const long long*>(offsets), static_cast<unsigned char*>(out));
+    GOLCHK(hipGetLastError());
+    return FRAD_OK;
+}
+
+int frad_p1_golomb_decode(const void* bodies, const int64_t* offsets, int64_t n_frames, int32_t N, int32_t C,
+                          int32_t* q, int32_t* tq, int32_t* status, void* stream) {
+    if (n_frames < 0 || N < 1 || C < 1 || C > 256) return FRAD_E_INVALID;
+    if (n_frames == 0) return FRAD_OK;
+    if (!bodies || !offsets || !q || !tq) return FRAD_E_INVALID;
+    const long long lanes = 2 * (long long)n_frames, blocks = (lanes + 63) / 64;
+    if (blocks > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_gol_decode, dim3((unsigned)blocks), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<const unsigned char*>(bodies),
+                       reinterpret_cast<const long long*>(offsets), (long long)n_frames, (long long)N * C, 27LL * C, q, tq, status);
+    GOLCHK(hipGetLastError());
+    return FRAD_OK;
+}
+
+}  // extern "C"

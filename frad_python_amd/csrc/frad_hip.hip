@@ -230,7 +230,7 @@ const char* frad_strerror(int status) {
     switch (status) {
         case FRAD_OK: return "ok";
         case FRAD_E_INVALID: return "invalid argument";
-        case FRAD_E_UNSUPPORTED: return "geometry not supported by the HIP transform core (frame too large for LDS, or profile-1 float input)";
+        case FRAD_E_UNSUPPORTED: return "geometry not supported by the HIP transform core (more than 2^30 values per frame, or a batch beyond the grid limit)";
         case FRAD_E_HIP: return "HIP runtime error (no MI355X visible, or a launch failed); see frad_last_hip_error()";
         case FRAD_E_NOMEM: return "out of device memory";
         default: return "unknown frad_status";
@@ -387,7 +387,11 @@ int frad_p0_analogue_checked(const void* pcm, int32_t pcm_dtype, int64_t n_frame
     if (c.ok) {
         Tables tb; rc = get_tables(c.log2m, f32, tb);
         if (rc != FRAD_OK) return rc;
-        if (c.cg < C && bits == 12 && ((C & 1) || (c.cg & 1))) return FRAD_E_UNSUPPORTED;
+        if (c.cg < C && bits == 12 && ((C & 1) || (c.cg & 1))) {       // pairs of values would straddle channel groups
+            const int r = global_p0_analogue(in, out, absmax, g, flags, s);
+            if (r == FRAD_E_HIP) g_last_hip = global_last_hip_error();
+            return r;
+        }
         g.fpb = c.fpb; g.cg = c.cg;
         if (c.cg == C && ai) {                               // quad stage-in needs whole 16-byte rows / row groups
             const int rb = C << lg;
@@ -408,7 +412,11 @@ int frad_p0_analogue_checked(const void* pcm, int32_t pcm_dtype, int64_t n_frame
             if (r == 1) { HIPCHK(hipGetLastError()); return FRAD_OK; }
         }
         const size_t per_frame = 2 * (size_t)N * C * (f32 ? 4 : 8);
-        if (per_frame > (size_t)kLdsBytes) return FRAD_E_UNSUPPORTED;
+        if (per_frame > (size_t)kLdsBytes) {                 // wider than a CU's LDS: HBM workspaces (frad_global.hip)
+            const int r = global_p0_analogue(in, out, absmax, g, flags, s);
+            if (r == FRAD_E_HIP) g_last_hip = global_last_hip_error();
+            return r;
+        }
         DirectTable d; rc = get_direct(N, d);
         if (rc != FRAD_OK) return rc;
         if (absmax) HIPCHK(hipMemsetAsync(absmax, 0, sizeof(double) * (size_t)n_frames, s));
@@ -463,7 +471,11 @@ int frad_p0_digital(const void* payload, int64_t payload_stride, int64_t n_frame
         if (r < 0) { if (r == FRAD_E_HIP) g_last_hip = blue_last_hip_error(); return r; }
         if (r == 1) { HIPCHK(hipGetLastError()); return FRAD_OK; }
         const size_t per_frame = 2 * (size_t)N * C * 8;
-        if (per_frame > (size_t)kLdsBytes) return FRAD_E_UNSUPPORTED;
+        if (per_frame > (size_t)kLdsBytes) {
+            const int r = global_p0_digital(in, pcm_out, g, flags, s);
+            if (r == FRAD_E_HIP) g_last_hip = global_last_hip_error();
+            return r;
+        }
         DirectTable d; rc = get_direct(N, d);
         if (rc != FRAD_OK) return rc;
         g.fpb = direct_fpb(n_frames, C, per_frame);

@@ -87,6 +87,10 @@ int launch_p0_inv_wave(hipStream_t s, const unsigned char* pay, double* out, con
                        unit_root_fn unit);
 void wave_blob_build(std::vector<unsigned char>& bytes, unit_root_fn unit);
 void wave_clear();
+// workspace path of last resort (frad_global.hip): frames that no LDS-resident kernel can hold run through HBM buffers
+int global_p0_analogue(const unsigned char* pcm, unsigned char* payload, double* absmax, const Geom& g, uint32_t flags, hipStream_t s);
+int global_p0_digital(const unsigned char* payload, double* out, const Geom& g, uint32_t flags, hipStream_t s);
+int global_last_hip_error();
 // CRC-32 tables (frad_crc.hip)
 void crc_clear();
 void p1_clear();         // profile-1 band maps (frad_p1.hip)

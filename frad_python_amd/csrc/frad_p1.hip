@@ -78,6 +78,7 @@ int make_tables(int N, int srate, int bits, double loss_level, P1Tables& tb) {
     }
     tb.scale = ldexp(1.0, p1_scale_bits(bits) - 1);
     tb.loss = fabs(loss_level) > 0.125 ? fabs(loss_level) : 0.125;
+    tb.f32 = 0;
     return band_table(N, sr, tb, &tb.band_of);
 }
 
@@ -128,6 +129,17 @@ int p1_group(const FastCfg& c, int N, int C, size_t kLdsBytes_, size_t& lds) {
     return cg;
 }
 
+// whole frames per block: shrink the block until the transform buffers plus the quantiser's scratch fit; false = this
+// geometry goes to the channel-group, direct or workspace kernels instead
+bool p1_fast_fits(FastCfg& c, int N, int C) {
+    if (!c.ok || c.cg != C) return false;
+    const size_t M = (size_t)1 << c.log2m;
+    while (c.fpb > 1 && (size_t)c.fpb * C * M * 16 + p1_scratch_bytes(c.fpb * C, N) > 80 * 1024) c.fpb -= 1;
+    c.threads = c.fpb * C * c.team;
+    if (c.threads > 1024 || c.threads % 64) return false;
+    return (size_t)c.fpb * C * M * 16 + p1_scratch_bytes(c.fpb * C, N) <= 160 * 1024;
+}
+
 Geom p1_geom(long long n_frames, int N, int C, long long stride, int n_valid, int dtype, uint32_t flags) {
     Geom g{};
     g.n_frames = n_frames; g.frame_stride = stride; g.payload_stride = 0; g.N = N; g.C = C; g.bits = 32; g.le = 0;
@@ -156,23 +168,22 @@ int frad_p1_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
     if (n_frames == 0) return FRAD_OK;
     if (!pcm || !q || !tq) return FRAD_E_INVALID;
     const int kind = pcm_dtype >> 3, lg = (pcm_dtype >> 1) & 3;
-    if (kind == 2 && lg <= 2) return FRAD_E_UNSUPPORTED;          // f32 / f16 PCM: the reference's mixed-precision path
+    if ((kind == 2 && lg == 0) || (lg == 0 && (pcm_dtype & 1))) return FRAD_E_INVALID;
     P1Tables tb;
     int rc = make_tables(N, srate, bits, loss_level, tb);
     if (rc != FRAD_OK) return rc;
+    // f32 / f16 PCM is not widened by the reference (pcmformat.py:35): float32 DCT, float32 band statistics, float64
+    // quantiser.  Here the DCT runs in float64 on the exactly widened samples and its result is rounded to float32.
+    tb.f32 = (kind == 2 && lg <= 2) ? 1 : 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Geom g = p1_geom(n_frames, N, C, frame_stride, n_valid, pcm_dtype, flags);
     const int ai = ((reinterpret_cast<uintptr_t>(pcm) & 15u) == 0 && (((frame_stride * C) << lg) % 16 == 0) &&
                     ((((long long)N * C) << lg) % 16 == 0)) ? 1 : 0;
     const unsigned char* in = static_cast<const unsigned char*>(pcm);
     FastCfg c = fast_cfg(N, C, false);
-    if (c.ok && c.cg == C) {
+    if (p1_fast_fits(c, N, C)) {
         const int M = 1 << c.log2m;
-        while (c.fpb > 1 && (size_t)c.fpb * C * M * 16 + p1_scratch_bytes(c.fpb * C, N) > 80 * 1024) { c.fpb -= 1; }
-        c.threads = c.fpb * C * c.team;
-        if (c.threads > 1024 || c.threads % 64) return FRAD_E_UNSUPPORTED;
         const size_t lds = (size_t)c.fpb * C * M * 16 + p1_scratch_bytes(c.fpb * C, N);
-        if (lds > kLds) return FRAD_E_UNSUPPORTED;
         Tables t; rc = get_tables(c.log2m, false, t);
         if (rc != FRAD_OK) return rc;
         g.fpb = c.fpb;
@@ -204,7 +215,12 @@ int frad_p1_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
         }
     } else {
         const size_t lds = 2 * (size_t)N * C * 8 + p1_scratch_bytes(C, N);
-        if (lds > kLds || n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
+        if (n_frames > 0x7fffffffLL / C) return FRAD_E_UNSUPPORTED;
+        if (lds > kLds) {
+            rc = global_p1_analogue(in, q, tq, g, tb, s);
+            if (rc == FRAD_E_HIP) g_last = global_last_hip_error();
+            return rc;
+        }
         DirectTable d; rc = get_direct(N, d);
         if (rc != FRAD_OK) return rc;
         dim3 grid((unsigned)n_frames);
@@ -227,13 +243,9 @@ int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32
     hipStream_t s = static_cast<hipStream_t>(stream);
     Geom g = p1_geom(n_frames, N, C, N, N, FRAD_PCM_F64LE, 0);
     FastCfg c = fast_cfg(N, C, false);
-    if (c.ok && c.cg == C) {
+    if (p1_fast_fits(c, N, C)) {
         const int M = 1 << c.log2m;
-        while (c.fpb > 1 && (size_t)c.fpb * C * M * 16 + p1_scratch_bytes(c.fpb * C, N) > 80 * 1024) { c.fpb -= 1; }
-        c.threads = c.fpb * C * c.team;
-        if (c.threads > 1024 || c.threads % 64) return FRAD_E_UNSUPPORTED;
         const size_t lds = (size_t)c.fpb * C * M * 16 + p1_scratch_bytes(c.fpb * C, N);
-        if (lds > kLds) return FRAD_E_UNSUPPORTED;
         Tables t; rc = get_tables(c.log2m, false, t);
         if (rc != FRAD_OK) return rc;
         g.fpb = c.fpb;
@@ -265,7 +277,12 @@ int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32
         }
     } else {
         const size_t lds = 2 * (size_t)N * C * 8 + p1_scratch_bytes(C, N);
-        if (lds > kLds || n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
+        if (n_frames > 0x7fffffffLL / C) return FRAD_E_UNSUPPORTED;
+        if (lds > kLds) {
+            rc = global_p1_digital(q, tq, pcm_out, g, tb, s);
+            if (rc == FRAD_E_HIP) g_last = global_last_hip_error();
+            return rc;
+        }
         DirectTable d; rc = get_direct(N, d);
         if (rc != FRAD_OK) return rc;
         allow_lds(k_p1_inv_direct<0>, lds);

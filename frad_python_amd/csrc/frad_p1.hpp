@@ -23,7 +23,25 @@ struct P1Tables {
     double scale;                // 2^(bits-1)                            (profile1.py:9-10)
     double loss;                 // max(|loss_level|, 0.125)              (profile1.py:20)
     int nb_used;                 // bands before the first empty one      (p1tools.py:22: break)
+    int f32;                     // float32 / float16 PCM: the reference does not widen it (pcmformat.py:35), so its DCT
+                                 // and band energies are float32 and only the divide + quantiser are float64
 };
+
+// Band energy -> masking threshold of one band (p1tools.py:18-33).  `f32`: numpy's types on float32 coefficients --
+// mean, sqrt and the 0.8 power stay float32, and the product with the loss level does too when the signal term wins.
+__device__ __forceinline__ double p1_band_threshold(double energy, int bins, double floor_, double loss, int f32) {
+    if (!f32) {
+        const double sfq = pow(sqrt(energy / (double)bins), 0.8);
+        return (floor_ > sfq ? floor_ : sfq) * loss;
+    }
+    const float mean = (float)(energy / (double)bins);
+    const float sfq = powf(sqrtf(mean), 0.8f);
+    return floor_ > (double)sfq ? floor_ * loss : (double)(sfq * (float)loss);
+}
+
+// frad_global.hip: profile 1 through HBM workspaces (frames wider than a CU's LDS at a non-power-of-two size)
+int global_p1_analogue(const unsigned char* pcm, int32_t* q, int32_t* tq, const Geom& g, const P1Tables& tb, hipStream_t s);
+int global_p1_digital(const int32_t* q, const int32_t* tq, double* out, const Geom& g, const P1Tables& tb, hipStream_t s);
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
     return u2d(wave_allreduce_u64(d2u(v), [](u64 a, u64 b) { return d2u(u2d(a) + u2d(b)); }));
@@ -100,7 +118,7 @@ __device__ __forceinline__ double p1_spread(const P1Lds& l, int cf, int k) {
 template <int SH>
 __device__ FRAD_NOINLINE void p1_quantise(int smem_off, int scratch_off, int slots, double scale, double loss, int nb_used, const Geom& g,
                                           long long f0, int nfl, int32_t* __restrict__ q, int32_t* __restrict__ tq,
-                                          int c0, int cw, int cfs) {
+                                          int c0, int cw, int cfs, int f32 = 0) {
     FRAD_DYN_SMEM(base);
     unsigned char* smem = base + smem_off;
     const int N = g.N, C = g.C, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
@@ -110,7 +128,8 @@ __device__ FRAD_NOINLINE void p1_quantise(int smem_off, int scratch_off, int slo
         const int b = task % P1_BANDS, cf = task / P1_BANDS;
         const int a = l.edge[b], e = l.edge[b + 1];
         double acc = 0.0;
-        for (int k = a + lane; k < e; k += 64) { const double v = xslot<double, SH>(smem, cf, slots, k) * scale; acc = fma(v, v, acc); }
+        if (f32) for (int k = a + lane; k < e; k += 64) { const float v = (float)xslot<double, SH>(smem, cf, slots, k) * (float)scale; acc += (double)(v * v); }
+        else for (int k = a + lane; k < e; k += 64) { const double v = xslot<double, SH>(smem, cf, slots, k) * scale; acc = fma(v, v, acc); }
         acc = wave_sum_f64(acc);
         if (lane == 0) l.thres[cf * P1_BANDS + b] = acc;
     }
@@ -119,10 +138,7 @@ __device__ FRAD_NOINLINE void p1_quantise(int smem_off, int scratch_off, int slo
     for (int i = threadIdx.x; i < nfl * cw * P1_BANDS; i += blockDim.x) {
         const int b = i % P1_BANDS;
         double t = 0.0;
-        if (b < nb_used) {
-            const double sfq = pow(sqrt(l.thres[i] / (double)(l.edge[b + 1] - l.edge[b])), 0.8);
-            t = (sfq > l.floor_[b] ? sfq : l.floor_[b]) * loss;
-        }
+        if (b < nb_used) t = p1_band_threshold(l.thres[i], l.edge[b + 1] - l.edge[b], l.floor_[b], loss, f32);
         l.thres[i] = t;
     }
     __syncthreads();
@@ -139,7 +155,8 @@ __device__ FRAD_NOINLINE void p1_quantise(int smem_off, int scratch_off, int slo
     const int NW = N * cw;
     for (int i = threadIdx.x; i < nfl * NW; i += blockDim.x) {
         const int fl = i / NW, r = i - fl * NW, k = r / cw, j = r - k * cw, cf = fl * cw + j;
-        const double x = xslot<double, SH>(smem, cf, slots, k);
+        double x = xslot<double, SH>(smem, cf, slots, k);
+        if (f32) x = (double)(float)x;
         const double div = p1_spread(l, cf, k);
         const double m = (div == 0.0) ? 0.0 * x : x / div;                // x / inf keeps the sign of x
         q[(f0 + fl) * (long long)N * C + (long long)k * C + c0 + j] = (int32_t)rint(p1_quant(m * scale));
@@ -188,7 +205,7 @@ k_p1_fwd(const unsigned char* __restrict__ pcm, int32_t* __restrict__ q, int32_t
     fft_team<double, LOG2M, false>(buf, t, tw);
     dct_post<double, LOG2M>(buf, t, post);
     __syncthreads();
-    p1_quantise<SH>(0, g.fpb * g.C * SLOTS * 16, SLOTS, tb.scale, tb.loss, tb.nb_used, g, f0, nfl, q, tq, 0, g.C, g.fpb * g.C);
+    p1_quantise<SH>(0, g.fpb * g.C * SLOTS * 16, SLOTS, tb.scale, tb.loss, tb.nb_used, g, f0, nfl, q, tq, 0, g.C, g.fpb * g.C, tb.f32);
 }
 
 template <int LOG2M, int MAXT>
@@ -232,7 +249,7 @@ k_p1_fwd_grp(const unsigned char* __restrict__ pcm, int32_t* __restrict__ q, int
         fft_team<double, LOG2M, false>(buf, tt, tw);
         dct_post<double, LOG2M>(buf, tt, post);
         __syncthreads();
-        p1_quantise<SH>(0, scratch_off, SLOTS, tb.scale, tb.loss, tb.nb_used, g, f0, 1, q, tq, c0, cgn, cg);
+        p1_quantise<SH>(0, scratch_off, SLOTS, tb.scale, tb.loss, tb.nb_used, g, f0, 1, q, tq, c0, cgn, cg, tb.f32);
         __syncthreads();
     }
 }
@@ -285,7 +302,7 @@ __global__ void __launch_bounds__(256) k_p1_fwd_direct(const unsigned char* __re
         X[(long long)c * N + k] = acc * inv_n;
     }
     __syncthreads();
-    p1_quantise<-1>(N * C * 8, 2 * N * C * 8, N, tb.scale, tb.loss, tb.nb_used, g, f0, 1, q, tq, 0, C, C);
+    p1_quantise<-1>(N * C * 8, 2 * N * C * 8, N, tb.scale, tb.loss, tb.nb_used, g, f0, 1, q, tq, 0, C, C, tb.f32);
 }
 
 template <int UNUSED>

@@ -91,35 +91,38 @@ class Encoder:
         return b"".join(out)
 
     def inner(self, stream: bytes, flush: bool) -> EncodeResult:
-        self.buffer += stream
+        """Transactional: `buffer` / `have_carry` change only after every launch of this call has succeeded, so a device
+        error leaves the encoder exactly as it was before the call (nothing consumed, nothing half-emitted)."""
         if not self.init:
+            self.buffer += stream
             return EncodeResult(b"", 0)
+        buf, have_carry = self.buffer + stream, self.have_carry
         compact_prof = self.asfh.profile in profiles.COMPACT
         n_eff = compact.get_samples_min_ge(self.fsize) if compact_prof else self.fsize
         ratio = self.asfh.overlap_ratio
         cut = n_eff * (ratio - 1) // ratio if (compact_prof and ratio > 1) else n_eff      # encoder.py:48
         step = self.pcm_format.itemsize * self.channels
-        have = len(self.buffer) // step
+        have = len(buf) // step
         ret, samples = b"", 0
         # ---- whole frames (encoder.py:72-104, batched): frame i covers sample-frames [i*cut, i*cut + n_eff)
         if have >= n_eff:
             k = (have - n_eff) // cut + 1
-            ret += self._encode_frames(self.buffer[:((k - 1) * cut + n_eff) * step], k, n_eff, cut, n_eff)
+            ret += self._encode_frames(buf[:((k - 1) * cut + n_eff) * step], k, n_eff, cut, n_eff)
             carry = n_eff - cut
-            samples += k * n_eff - (k - 1) * carry - (carry if self.have_carry else 0)
-            self.buffer = self.buffer[k * cut * step:]
-            self.have_carry = carry > 0
-        if not flush:
-            return EncodeResult(ret, samples)
-        # ---- flush (encoder.py:81, 89-91, 105): what is left (carry + remainder) becomes one short frame
-        have = len(self.buffer) // step
-        if have > 0:
-            carry = (n_eff - cut) if self.have_carry else 0
-            ret += self._encode_frames(self.buffer[:have * step], 1, have, have, have)
-            samples += have - carry
+            samples += k * n_eff - (k - 1) * carry - (carry if have_carry else 0)
+            buf = buf[k * cut * step:]
+            have_carry = carry > 0
+        if flush:
+            # ---- flush (encoder.py:81, 89-91, 105): what is left (carry + remainder) becomes one short frame
+            have = len(buf) // step
+            if have > 0:
+                carry = (n_eff - cut) if have_carry else 0
+                ret += self._encode_frames(buf[:have * step], 1, have, have, have)
+                samples += have - carry
+                ret += self.asfh.force_flush()
+            buf, have_carry = b"", False
             ret += self.asfh.force_flush()
-        self.buffer, self.have_carry = b"", False
-        ret += self.asfh.force_flush()
+        self.buffer, self.have_carry = buf, have_carry
         return EncodeResult(ret, samples)
 
     def process(self, stream: bytes) -> EncodeResult:

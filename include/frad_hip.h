@@ -137,6 +137,30 @@ int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32
 int frad_p1_overlap_add(const double* frames, int64_t n_frames, int32_t N, int32_t C, int32_t overlap_ratio,
                         const double* prev_tail, double* ola_out, double* next_tail, void* stream);
 
+/* ---- profile 1: Exp-Golomb-Rice stage (row 8f #2) ------------------------------------------------
+ * frad_p1_golomb_encode == the two exp_golomb_rice_encode calls and the struct.pack of profile1.py:43-45
+ * (tools/p1tools.py:46-60): per frame the pre-deflate body  '>I' len(thres_gol) + thres_gol + freqs_gol  is
+ * written at bodies + i*body_stride and its length to body_bytes[i].  body_stride >= frad_p1_golomb_bound(N, C)
+ * (the worst case: k is taken from the frame's maximum, so a value costs at most k + 3 <= 35 bits), a multiple
+ * of 4; `bodies` 4-byte aligned.  q / tq as frad_p1_analogue writes them.  zlib's deflate stays on the host.
+ *
+ * frad_rows_compact: offsets[0] = 0, offsets[i+1] = offsets[i] + row_bytes[i] (n_rows + 1 entries), and, when `out`
+ * is not NULL, row i's first row_bytes[i] bytes copied to out + offsets[i] -- the batch then goes to the host as ONE
+ * copy of exactly the bytes deflate needs.
+ *
+ * frad_p1_golomb_decode == the two exp_golomb_rice_decode calls of profile1.py:59-64 (p1tools.py:62-74) plus untrim
+ * (profile1.py:12-13): frame i's inflated body is bodies[offsets[i] .. offsets[i+1]); q [n_frames, N, C] and
+ * tq [n_frames, 27, C] receive the decoded integers, zero-filled where the stream ends early and cut at N*C / 27*C
+ * values; values outside int32 (only a corrupt stream has them) saturate.  status[i] (may be NULL) = 1 when the body
+ * is shorter than its length word.                                                                       */
+size_t frad_p1_golomb_bound(int32_t N, int32_t C);
+int frad_p1_golomb_encode(const int32_t* q, const int32_t* tq, int64_t n_frames, int32_t N, int32_t C,
+                          void* bodies, int64_t body_stride, int64_t* body_bytes, void* stream);
+int frad_rows_compact(const void* rows, int64_t row_stride, const int64_t* row_bytes, int64_t n_rows, void* out,
+                      int64_t* offsets, void* stream);
+int frad_p1_golomb_decode(const void* bodies, const int64_t* offsets, int64_t n_frames, int32_t N, int32_t C,
+                          int32_t* q, int32_t* tq, int32_t* status, void* stream);
+
 /* ---- frame header checksum (row 8f #1) --------------------------------------------------------
  * crc_out[i] = zlib.crc32 of the `nbytes` payload bytes of frame i (at data + i*stride), the value
  * ASFH.write puts into a lossless frame's header (src/libfrad/tools/asfh.py:51-73), so a batch's

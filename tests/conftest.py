@@ -35,5 +35,10 @@ def g4():
 
 
 @pytest.fixture(scope="session")
+def g6():
+    return load_npz("g6_p1_more.npz")
+
+
+@pytest.fixture(scope="session")
 def g5():
     return load_npz("g5_edge.npz")

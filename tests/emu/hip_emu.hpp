@@ -150,6 +150,8 @@ enum { hipDeviceAttributeMultiprocessorCount = 1 };
 inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 3; return hipSuccess; }
 template <typename P> inline hipError_t hipMalloc(P** p, size_t n) { *p = static_cast<P*>(std::aligned_alloc(64, (n + 63) / 64 * 64)); return *p ? 0 : 2; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+template <typename P> inline hipError_t hipMallocAsync(P** p, size_t n, hipStream_t) { return hipMalloc(p, n); }
+inline hipError_t hipFreeAsync(void* p, hipStream_t) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }

@@ -1,7 +1,7 @@
 """Randomised differential test on the MI355X: profile 0 / 4 over random geometry (frame length incl. odd
 sizes, channels, PCM format, storage depth, endianness, buffer offsets) against the oracle, under the same
-tolerance contract as tests/test_parity.py.  Fixed seed; geometries beyond the documented LDS limits must
-be refused with FRAD_E_UNSUPPORTED (-2), never mis-computed."""
+tolerance contract as tests/test_parity.py.  Fixed seed.  Nothing legal is refused: frames wider than a CU's LDS run
+through HBM workspaces (csrc/frad_global.hip)."""
 import os
 
 import numpy as np
@@ -17,14 +17,9 @@ FORMATS = ["s16le", "s16be", "u8", "s8", "s32le", "u16le", "f32le", "f32be", "f6
 
 
 def _check(be, rng, profile, N, C, F, fmt, bits, le, offset, hop=None, pad=0, raw_be=True):
-    from frad_python_amd._lib import FradError
     hop = N if hop is None else hop
     raw = synth.to_pcm(rng.uniform(-1, 1, ((F - 1) * hop + N, C)), fmt)
-    try:
-        pay, am = be.analogue(profile, raw, fmt, F, N, C, bits, le, offset=offset, frame_stride=hop, pad_stride=pad, raw_be=raw_be)
-    except FradError as e:
-        assert e.status == -2, (profile, N, C, F, fmt, bits, le, offset, str(e))
-        return "refused"
+    pay, am = be.analogue(profile, raw, fmt, F, N, C, bits, le, offset=offset, frame_stride=hop, pad_stride=pad, raw_be=raw_be)
     ref = oracle_frames(fo, profile, raw, fmt, F, N, C, bits, le, frame_stride=hop, raw_be=raw_be)
     f32 = fmt.startswith(("f32", "f16"))
     lg = max(np.log2(N), 1.0)
@@ -42,12 +37,7 @@ def _check(be, rng, profile, N, C, F, fmt, bits, le, offset, hop=None, pad=0, ra
             continue
         tol = (store + (8 * EPS32 if f32 else 8 * EPS64) * lg) * max(np.max(np.abs(wv[fin])), 1e-300)
         assert np.max(np.abs(gv[fin] - wv[fin])) <= 2 * tol, ("p0 payload", N, C, F, fmt, bits, le, offset, f)
-    try:
-        dec = be.digital(profile, np.stack([r[0] for r in ref]), F, N, C, bits, le, offset=offset)
-    except FradError as e:
-        # what encodes must decode, except beyond the documented limit (non-power-of-two N > 4096 with N*C*16 > 160 KiB)
-        assert e.status == -2 and N > 4096 and (N & (N - 1)), ("decode refused", profile, N, C, F, fmt, bits, le, offset)
-        return "refused"
+    dec = be.digital(profile, np.stack([r[0] for r in ref]), F, N, C, bits, le, offset=offset)
     for f in range(F):
         if profile == 4:
             assert np.array_equal(dec[f], ref[f][1]), ("p4 decode", N, C, F, fmt, bits, le, offset, f)
@@ -60,15 +50,18 @@ def _check(be, rng, profile, N, C, F, fmt, bits, le, offset, hop=None, pad=0, ra
 def test_random_geometries_against_oracle():
     be = GpuBackend()
     rng = np.random.default_rng(int(os.environ.get("FRAD_FUZZ_SEED", "20261004")))
-    done = {"ok": 0, "refused": 0}
-    pow2 = [128, 256, 512, 1024, 2048, 4096, 8192]
+    done = {"ok": 0}
+    pow2 = [128, 256, 512, 1024, 2048, 4096, 8192, 16384]
     rounds = int(os.environ.get("FRAD_FUZZ_N", "220"))       # a longer one-off hunt: FRAD_FUZZ_N=3000 FRAD_FUZZ_SEED=...
     for i in range(rounds):
         profile = int(rng.choice([0, 0, 4]))
-        kind = rng.integers(0, 3)
-        N = int(rng.choice(pow2)) if kind == 0 else int(rng.integers(1, 3000)) if kind == 1 else int(rng.choice([896, 1920, 441, 1000, 1536, 2047, 2049, 96, 95, 97]))
+        kind = rng.integers(0, 3) if i % 20 else 3          # kind 3: an odd frame wider than a CU's LDS (a long clip's tail)
+        N = int(rng.choice(pow2)) if kind == 0 else int(rng.integers(1, 3000)) if kind == 1 else \
+            int(rng.integers(4097, 16384)) if kind == 3 else int(rng.choice([896, 1920, 441, 1000, 1536, 2047, 2049, 96, 95, 97]))
         C = int(rng.choice([1, 1, 2, 2, 2, 3, 5, 6, 8]))
         F = int(rng.choice([1, 2, 3, 7, 33]))
+        if kind == 3:
+            F, C = int(rng.choice([1, 2])), int(rng.choice([1, 2, 3]))
         while N * C * F > 600000:
             F = max(1, F // 2)
             if F == 1 and N * C > 600000:
@@ -84,31 +77,25 @@ def test_random_geometries_against_oracle():
         if (i + 1) % 5000 == 0:
             print("fuzz progress:", i + 1, done, flush=True)
     print("fuzz:", rounds, "rounds", done)
-    assert done["ok"] >= 0.65 * rounds, done
+    assert done["ok"] == rounds, done
 
 
 def test_random_profile1_geometries_against_oracle():
     """Profile 1 (K7 / K8) over random legal compact frame sizes, rates, depths, loss levels and channel counts."""
     from frad_python_amd.fourier import profiles
-    from frad_python_amd._lib import FradError
     from test_parity_p1 import _check_ints
     be = GpuBackend()
     rng = np.random.default_rng(int(os.environ.get("FRAD_FUZZ_SEED", "20261004")) + 1)
     rounds = int(os.environ.get("FRAD_FUZZ_N", "220")) // 4
     sizes = list(profiles.compact.SAMPLES)                  # every legal compact frame size (profiles.py:14-23), up to 28 672
     dt = fo.pcm_dtype("s16le")
-    ok = refused = 0
+    ok = 0
     for _ in range(rounds):
         N = int(rng.choice(sizes)); C = int(rng.choice([1, 2, 2, 3, 6])); F = int(rng.choice([1, 2, 5]))
         srate = int(rng.choice(profiles.compact.SRATES)); bits = int(rng.choice([8, 12, 16, 24, 32]))
         loss = float(1.25 ** int(rng.integers(0, 21)) / 19.0 + 0.5)
         raw = synth.to_pcm(synth.harmonic_mix(F * N, C, srate, seed=int(rng.integers(0, 1 << 30))) * rng.uniform(0.05, 1.0), "s16le")
-        try:
-            q, tq = be.p1_analogue(raw, "s16le", F, N, C, bits, srate, loss)
-        except FradError as e:
-            assert e.status == -2, (N, C, F, srate, bits, loss, str(e))
-            refused += 1
-            continue
+        q, tq = be.p1_analogue(raw, "s16le", F, N, C, bits, srate, loss)        # every legal geometry runs (refused == 0)
         for f in range(F):
             wq, wt, aux = fo.p1_analogue_pre(fo.to_f64(raw[f * N:(f + 1) * N], dt), bits, srate, loss)
             _check_ints(q[f].reshape(-1), wq, f"q {(N, C, srate, bits, loss, f)}")
@@ -117,5 +104,5 @@ def test_random_profile1_geometries_against_oracle():
             ref = fo.p1_digital_post(wq, wt, fo.P1_DEPTHS.index(bits), C, srate, N)
             assert np.max(np.abs(dec - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref))), (N, C, srate, bits, loss, f)
         ok += 1
-    print("p1 fuzz:", rounds, "rounds", {"ok": ok, "refused": refused})
-    assert ok >= 0.6 * rounds
+    print("p1 fuzz:", rounds, "rounds", {"ok": ok, "refused": 0})
+    assert ok == rounds

@@ -185,3 +185,37 @@ def test_batched_baseline_is_bitwise_the_per_frame_oracle():
                 frad, idx, ch, sr = fo.p0_analogue(fo.to_f64(raw[f * N:(f + 1) * N], dt), bits, 48000, le)
                 assert pay[f].tobytes() == frad, (bits, le, f)
                 assert np.array_equal(dec[f], fo.p0_digital(frad, idx, ch, le)), (bits, le, f)
+
+
+def test_g6_float_pcm_wide_frames_golomb_and_from_f64(g6):
+    """Round-2 fixtures (oracle/gen_golden_g6.py): profile 1 on float PCM and at wide compact sizes, the Golomb coder on
+    long vectors, from_f64 for every integer format -- the oracle equals the reference bit for bit."""
+    def padded(a, n):
+        out = np.zeros(n, np.int64); out[:a.size] = a
+        return out
+    for fmt in ("f32le", "f32be", "f16le"):
+        for (N, C, sr) in ((2048, 2, 48000), (640, 1, 32000)):
+            raw = g6[f"f_{fmt}_{N}_{C}_in"]
+            pcm = np.frombuffer(raw.tobytes(), fo.pcm_dtype(fmt)).reshape(-1, C)
+            for lv, ll in (("a", 0.553), ("b", 5.0)):
+                q, tq, aux = fo.p1_analogue_pre(fo.to_f64(pcm, fo.pcm_dtype(fmt)), 16, sr, ll)
+                assert aux["freqs"].dtype == np.float32
+                assert np.array_equal(q, padded(g6[f"f_{fmt}_{N}_{C}_{lv}_q"], N * C)), (fmt, N, lv)
+                assert np.array_equal(tq, padded(g6[f"f_{fmt}_{N}_{C}_{lv}_tq"], 27 * C)), (fmt, N, lv)
+    for (N, C, sr) in ((10240, 1, 48000), (5120, 2, 44100), (2560, 5, 96000)):
+        raw = g6[f"w_{N}_{C}_in"]
+        q, tq, aux = fo.p1_analogue_pre(fo.to_f64(raw, fo.pcm_dtype("s16le")), 16, sr, 1.0)
+        assert np.array_equal(q, padded(g6[f"w_{N}_{C}_q"], N * C)) and np.array_equal(tq, padded(g6[f"w_{N}_{C}_tq"], 27 * C))
+        import zlib
+        assert zlib.decompress(fo.p1_pack(q, tq), wbits=-15) == g6[f"w_{N}_{C}_gol"].tobytes()      # the pre-deflate bytes
+        assert np.array_equal(fo.p1_digital_post(q, tq, 2, C, sr, N), g6[f"w_{N}_{C}_dec"])
+    for name in ("lap4k", "lap_wide", "sparse", "zeros", "one", "pow2", "big"):
+        data, want = g6[f"gol_{name}_data"], g6[f"gol_{name}_bytes"].tobytes()
+        assert fo.golomb_encode(data) == want, name
+        dec = fo.golomb_decode(want)
+        assert np.array_equal(padded(dec, data.size)[:data.size], data) and dec.size <= data.size + 8, name
+    ff = g6["ff_in"]
+    for fmt in ("u8", "u16le", "u16be", "u32le", "u32be", "s8", "s16le", "s16be", "s32le", "s32be", "s64le", "s64be", "u64le"):
+        with np.errstate(all="ignore"):
+            got = fo.from_f64(ff, fo.pcm_dtype(fmt))
+        assert str(got.dtype.str) == str(g6[f"ff_{fmt}_dtype"]) and got.tobytes() == g6[f"ff_{fmt}"].tobytes(), fmt

@@ -287,12 +287,8 @@ def test_golden_g2_frames_through_the_kernels(be, g2):
             raw = np.frombuffer(raw.tobytes(), dt)
         if DEPTHS_IDX(c["idx"]) != bits:
             continue                                          # escalated in the reference: host logic, tested apart
-        if c["profile"] == 0 and not fits_lds(N, C, fmt):
-            # one frame's channels exceed the 160 KiB LDS of a CU: the core refuses loudly (limits)
-            from frad_python_amd._lib import FradError
-            with pytest.raises(FradError):
-                be.analogue(0, np.ascontiguousarray(raw), fmt, 1, N, C, bits, le)
-            continue
+        if c["profile"] == 0 and not fits_lds(N, C, fmt) and be.name == "emu":
+            continue                                          # HBM-workspace path (frad_global.hip): too slow for the interpreter
         pay, am = be.analogue(c["profile"], np.ascontiguousarray(raw), fmt, 1, N, C, bits, le)
         want = arrs[c["key"] + "_frad"]
         if c["profile"] == 4:

@@ -154,3 +154,58 @@ def test_decoder_resync_and_truncation(kind):
     assert d.frames == 4 and not dec.is_empty()
     assert np.array_equal(d.pcm, want[:4 * 1024])
     assert dec.process(b"").frames == 0 and dec.broken_frame and dec.is_empty()
+
+
+@pytest.mark.parametrize("profile,frame_size,tail", [(0, 8192, 5121), (0, 8192, 8191), (0, 16384, 6000), (0, 4096, 1),
+                                                     (1, 16384, 9000), (1, 8192, 4500), (1, 16384, 16000)])
+def test_flush_tails_of_large_frames(kind, profile, frame_size, tail):
+    """A clip's last frame is whatever is left (encoder.py:72-93): with 8192 / 16384-sample frames the tail is an odd
+    length (profile 0) or pads to a non-power-of-two compact size (profile 1: 9000 -> 10240, 4500 -> 5120,
+    16000 -> 16384) that no LDS-resident kernel holds in stereo -- these used to raise FRAD_E_UNSUPPORTED in flush()."""
+    C = 2
+    pcm = synth.to_pcm(synth.harmonic_mix(frame_size + tail, C, 48000, seed=tail), "s16le").tobytes()
+    p = dict(profile=profile, srate=48000, channels=C, bits=16 if profile else 32, frame_size=frame_size, pcm_format="s16le")
+    out, samples = _encode(kind, pcm, 1 << 20, p)
+    ref = fo.encode_stream(pcm, **p)
+    assert samples == frame_size + tail
+    a, b = fo.decode_stream(out), fo.decode_stream(ref)
+    assert a.shape == b.shape and (profile == 1 or a.shape == (frame_size + tail, C))
+    if profile == 0:
+        assert len(out) == len(ref)
+        assert np.max(np.abs(a - b)) <= 1e-9                  # stored float32 words equal up to rounding ties
+    else:
+        psnr = 10 * np.log10(1.0 / max(np.mean((a - b) ** 2), 1e-300))
+        assert psnr > 100, psnr
+    got, frames = _decode(kind, ref, 1 << 20, C)
+    assert frames == 2 and got.shape == b.shape
+    assert np.max(np.abs(got - b)) <= 1e-12 * max(1.0, np.max(np.abs(b)))
+
+
+def test_encoder_is_transactional_on_device_errors():
+    """A failing launch must not consume input: buffer and carry state are committed only on success."""
+    class Boom(Exception):
+        pass
+
+    class FailingBridge:
+        def __init__(self):
+            from helpers import OracleBridge
+            self.inner, self.fail = OracleBridge(), True
+
+        def __getattr__(self, name):
+            fn = getattr(self.inner, name)
+
+            def call(*a, **k):
+                if self.fail:
+                    raise Boom(name)
+                return fn(*a, **k)
+            return call
+    pcm = synth.to_pcm(synth.harmonic_mix(5000, 2, 48000, seed=2), "s16le").tobytes()
+    br = FailingBridge()
+    enc = Encoder(0, 48000, 2, 32, 1024, "s16le", bridge=br)
+    with pytest.raises(Boom):
+        enc.process(pcm)
+    assert enc.buffer == b"" and not enc.have_carry
+    br.fail = False
+    out = enc.process(pcm).buf + enc.flush().buf
+    want = fo.encode_stream(pcm, profile=0, srate=48000, channels=2, bits=32, frame_size=1024, pcm_format="s16le")
+    assert out == want
