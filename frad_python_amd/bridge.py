@@ -108,6 +108,26 @@ class HipBridge:
                                             frame_stride=hop, n_valid=n_valid, raw_be_ints=raw_be_ints)
         return q.cpu().numpy(), tq.cpu().numpy()
 
+    def p1_encode_bodies(self, pcm: bytes, fmt, n_frames, N, C, bits, srate, loss_level, hop, n_valid, raw_be_ints=True) -> list:
+        """K7 + the Exp-Golomb-Rice stage on the device: the pre-deflate body of every frame (profile1.py:15-45),
+        one D2H copy of exactly those bytes; the integers never leave the device."""
+        q, tq = self.core.p1_analogue_batch(self._up(pcm), fmt, n_frames, N, C, bits, srate, loss_level,
+                                            frame_stride=hop, n_valid=n_valid, raw_be_ints=raw_be_ints)
+        flat, offsets = self.core.p1_golomb_encode_batch(q, tq)
+        off = offsets.cpu().numpy()
+        host = self._down_bytes(flat) if flat.numel() else b""
+        return [host[off[i]:off[i + 1]] for i in range(n_frames)]
+
+    def p1_decode_bodies(self, bodies: list, N, C, bits, srate) -> np.ndarray:
+        """Inflated frame bodies -> PCM: Golomb decode (profile1.py:59-64) and K8 on the device, one H2D copy of the
+        bodies (about a byte per coefficient instead of the four of an int32 array)."""
+        t = self.torch
+        off = np.zeros(len(bodies) + 1, np.int64)
+        np.cumsum([len(b) for b in bodies], out=off[1:])
+        flat = self._up(b"".join(bodies))
+        q, tq, status = self.core.p1_golomb_decode_batch(flat, t.from_numpy(off).to(self.device), N, C)
+        return self.core.p1_digital_batch(q, tq, N, C, bits, srate).cpu().numpy()
+
     def p1_decode(self, q: np.ndarray, tq: np.ndarray, N, C, bits, srate) -> np.ndarray:
         t = self.torch
         return self.core.p1_digital_batch(t.from_numpy(np.ascontiguousarray(q, np.int32)).to(self.device),

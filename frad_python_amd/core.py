@@ -209,6 +209,46 @@ def p1_analogue_batch(pcm: torch.Tensor, pcm_format: str, n_frames: int, N: int,
     return q, tq
 
 
+def p1_golomb_encode_batch(q: torch.Tensor, tq: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """The Exp-Golomb-Rice stage of ``profile1.analogue`` (profile1.py:43-45, p1tools.py:46-60) on the device.
+
+    ``q`` int32 [n_frames, N, C], ``tq`` int32 [n_frames, 27, C] -> ``(bodies uint8 [total], offsets int64
+    [n_frames + 1])``: frame i's pre-deflate body ('>I' len + Golomb(tq) + Golomb(q)) is
+    ``bodies[offsets[i]:offsets[i+1]]``.  Deflate stays on the host."""
+    _require_cuda(q, "q"); _require_cuda(tq, "tq")
+    if q.dtype != torch.int32 or tq.dtype != torch.int32 or not q.is_contiguous() or not tq.is_contiguous():
+        raise TypeError("q and tq must be contiguous int32")
+    n_frames, N, C = q.shape
+    lib = _lib.load()
+    stride = lib.p1_golomb_bound(N, C)
+    rows = torch.empty((n_frames, stride), dtype=torch.uint8, device=q.device)
+    nbytes = torch.empty(n_frames, dtype=torch.int64, device=q.device)
+    offsets = torch.empty(n_frames + 1, dtype=torch.int64, device=q.device)
+    with torch.cuda.device(q.device):
+        lib.p1_golomb_encode(q.data_ptr(), tq.data_ptr(), n_frames, N, C, rows.data_ptr(), stride, nbytes.data_ptr(), _stream_ptr())
+        lib.rows_compact(rows.data_ptr(), stride, nbytes.data_ptr(), n_frames, 0, offsets.data_ptr(), _stream_ptr())
+        total = int(offsets[-1].item()) if n_frames else 0      # the one host read: the size of the result
+        out = torch.empty(total, dtype=torch.uint8, device=q.device)
+        lib.rows_compact(rows.data_ptr(), stride, nbytes.data_ptr(), n_frames, out.data_ptr(), offsets.data_ptr(), _stream_ptr())
+    return out, offsets
+
+
+def p1_golomb_decode_batch(bodies: torch.Tensor, offsets: torch.Tensor, N: int, C: int):
+    """The two ``exp_golomb_rice_decode`` calls + ``untrim`` of ``profile1.digital`` (profile1.py:59-64,
+    p1tools.py:62-74): inflated bodies (uint8, frame i at ``offsets[i]:offsets[i+1]``) -> ``(q, tq, status)``."""
+    _require_cuda(bodies, "bodies"); _require_cuda(offsets, "offsets")
+    if bodies.dtype != torch.uint8 or offsets.dtype != torch.int64:
+        raise TypeError("bodies must be uint8 and offsets int64")
+    n_frames = offsets.numel() - 1
+    q = torch.empty((n_frames, N, C), dtype=torch.int32, device=bodies.device)
+    tq = torch.empty((n_frames, P1_BANDS, C), dtype=torch.int32, device=bodies.device)
+    status = torch.empty(max(n_frames, 1), dtype=torch.int32, device=bodies.device)
+    with torch.cuda.device(bodies.device):
+        _lib.load().p1_golomb_decode(bodies.data_ptr(), offsets.data_ptr(), n_frames, N, C, q.data_ptr(), tq.data_ptr(),
+                                     status.data_ptr(), _stream_ptr())
+    return q, tq, status[:n_frames]
+
+
 def p1_digital_batch(q: torch.Tensor, tq: torch.Tensor, N: int, C: int, bits: int, srate: int) -> torch.Tensor:
     """``profile1.digital`` from the decoded integers on (profile1.py:65-77): float64 [n_frames, N, C]."""
     _require_cuda(q, "q"); _require_cuda(tq, "tq")

@@ -15,10 +15,10 @@
 //                  Frames longer than a tile (4096 values) carry the partial last word into the next tile.
 //   k_rows_scan / k_rows_gather   exclusive scan of the body lengths and a gather into one contiguous buffer, so
 //                  that a batch goes back to the host (zlib) as ONE copy of exactly the bytes it needs.
-//   k_gol_decode   one LANE per (frame, stream): the code boundaries of a prefix code are a sequential dependency, so
-//                  the parallelism is across frames and the two streams of a frame; 64-bit window reader, values
-//                  written as they fall out.  Semantics of the reference decoder incl. its end conditions (a run of
-//                  zero bits ends the stream; a code cut short by the end of the buffer is read from the bits there).
+//   k_gol_decode   one LANE per frame (thresholds, then coefficients): the code boundaries of a prefix code are a
+//                  sequential dependency, so the parallelism is across frames; the wave stages 256 bytes of every
+//                  lane's stream through LDS per round.  Semantics of the reference decoder incl. its end conditions (a
+//                  run of zero bits ends the stream; a code cut short by the end of the buffer is read from the bits there).
 #include "frad_common.hpp"
 #include "../../include/frad_hip.h"
 
@@ -93,7 +93,7 @@ __device__ __forceinline__ u64 block_max(u64 v, u64* tmp) {
 }
 
 // one stream (n values at `data`) appended at bit position `pos` (byte aligned): k byte + codes + zero padding
-__device__ long long encode_stream(BitSink& s, long long pos, const int32_t* __restrict__ data, long long n, long long* tmp) {
+__device__ __forceinline__ long long encode_stream(BitSink& s, long long pos, const int32_t* __restrict__ data, long long n, long long* tmp) {
     u64 dmax = 0;
     for (long long i = threadIdx.x; i < n; i += blockDim.x) { const long long v = data[i]; const u64 a = (u64)(v < 0 ? -v : v); dmax = a > dmax ? a : dmax; }
     dmax = block_max(dmax, reinterpret_cast<u64*>(tmp));
@@ -180,49 +180,117 @@ __global__ void __launch_bounds__(GT) k_rows_gather(const unsigned char* __restr
 }
 
 // ---- decode --------------------------------------------------------------------------------------------------------
-struct BitReader {                                            // MSB-first reader over whole bytes, 64-bit window
-    const unsigned char* p; long long nbytes, next;           // next: first byte not yet in the window
-    u64 win; int have;                                        // the top `have` bits of `win` are the next unread bits
-    __device__ __forceinline__ void refill() {
-        while (have <= 56 && next < nbytes) { win |= (u64)p[next++] << (56 - have); have += 8; }
-    }
-    __device__ __forceinline__ long long left() const { return (long long)have + 8 * (nbytes - next); }
-    __device__ __forceinline__ void drop(int n) { win = n >= 64 ? 0 : win << n; have -= n; }
-};
+// One lane per frame, one wave per 64 frames.  A prefix code's boundaries are a sequential dependency, so the
+// parallelism is across frames; what must not happen is 64 lanes each waiting for their own global load (a wave stalls
+// as a whole).  So the wave moves the bitstreams in lock-step rounds: it copies the next 256 bytes of every lane's
+// stream into that lane's LDS row (coalesced: one row per load instruction), then every lane parses its row to the end
+// -- a resumable state machine, since a code may straddle two rounds -- and parks until the next round.
+constexpr int DCW = 64;                    // 32-bit words of a stream per round and lane
+constexpr int DPITCH = DCW + 1;            // row pitch in words: odd, so equal offsets of different rows hit different banks
+constexpr int DEC_LDS = 64 * DPITCH * 4;
 
 __device__ __forceinline__ int32_t sat32(long long v) { return v > 2147483647LL ? 2147483647 : v < -2147483648LL ? (int32_t)(-2147483647 - 1) : (int32_t)v; }
+__device__ __forceinline__ bool wave_any(bool v) { return wave_allreduce_u64(v ? 1ull : 0ull, [](u64 a, u64 b) { return a | b; }) != 0; }
 
-// decode one stream into out[0 .. cap), zero-fill what the stream does not cover
-__device__ void decode_stream(const unsigned char* p, long long len, int32_t* __restrict__ out, long long cap) {
+// the calling lane's stream: bytes [p, p + len) = k byte + code bits; out[0 .. cap) receives the values, zero-filled
+// (inlined, and the LDS taken from the kernel's own symbol: a pointer that went through a real call is generic, FLAT
+// accesses then wait on the global stores in flight as well)
+__device__ __forceinline__ void decode_stream_wave(const unsigned char* p, long long len, int32_t* __restrict__ out, long long cap) {
+    FRAD_DYN_SMEM(smem_);
+    uint32_t* rows = reinterpret_cast<uint32_t*>(smem_);
+    const int lane = threadIdx.x & 63;
+    uint32_t* row = rows + lane * DPITCH;
+    // ---- this lane's stream, seen as aligned 32-bit words
+    const int k = len >= 1 ? (int)p[0] : 0;
+    const unsigned char* bits = p + 1;
+    const long long nbytes = len >= 1 ? len - 1 : 0;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(bits);
+    const int lead = (int)(addr & 3);
+    const unsigned char* a0 = bits - lead;
+    const long long nwords = nbytes > 0 ? (lead + nbytes + 3) >> 2 : 0;
+    long long bits_left = nbytes * 8;                        // stream bits not yet moved into the window
+    u64 win = 0; int have = 0;                                // the top `have` bits of `win` are the next unread bits
+    // ---- parser state (survives the rounds)
+    int phase = 0; long long m = 0, want = 0; u64 val = 0; bool big = false;
+    bool active = nbytes > 0 && cap > 0;
     long long n_out = 0;
-    if (len >= 1) {
-        const int k = p[0];
-        BitReader r{p + 1, len - 1, 0, 0ull, 0};
-        while (n_out < cap) {
-            // m = index of the first '1' (p1tools.py:68); none left: stop
-            long long m = 0; bool found = false;
-            for (;;) {
-                r.refill();
-                if (r.have == 0) break;
-                if (r.win == 0) { m += r.have; r.have = 0; continue; }
-                const int z = __builtin_clzll(r.win);           // < have: only the top `have` bits can be set
-                m += z; r.drop(z); found = true; break;
+    const bool vec = (reinterpret_cast<uintptr_t>(out) & 15) == 0;    // four values per 16-byte store
+    int32_t o0 = 0, o1 = 0, o2 = 0;
+    for (long long round = 0; wave_any(active); ++round) {
+        // ---- fill: row r <- words [round * DCW, +DCW) of lane r's stream, big-endian to MSB-first; 16 rows' loads in
+        // flight at a time (one load instruction per row: 64 lanes x 4 bytes, coalesced)
+        for (int r0 = 0; r0 < 64; r0 += 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const u64 base = __shfl((u64)reinterpret_cast<uintptr_t>(a0), r0 + i, 64);
+                const long long nw = (long long)__shfl((u64)(active ? nwords : 0), r0 + i, 64);
+                const long long w = round * DCW + lane;
+                v[i] = 0;
+                if (w < nw) v[i] = *FRAD_GCPTR(uint32_t, reinterpret_cast<const unsigned char*>((uintptr_t)base) + 4 * w);
             }
-            if (!found) break;
-            // the codeword is data[:2m + k + 1]: the m zeros just skipped and m + k + 1 more bits -- fewer at the end of
-            // the buffer, where Python's slice is simply shorter
-            long long want = m + (long long)k + 1;
-            const long long left = r.left();
-            if (want > left) want = left;
-            u64 val = 0; bool big = false;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) rows[(r0 + i) * DPITCH + lane] = bswap32(v[i]);
+        }
+        FRAD_LDS_BARRIER();
+        // ---- parse this lane's row
+        int rw = 0;                                               // next word of the row
+        const long long row_words = nwords - round * DCW < DCW ? nwords - round * DCW : DCW;
+        auto refill = [&]() {
+            while (have <= 32 && rw < row_words) {
+                uint32_t w = row[rw++];
+                int valid = 32;
+                if (round == 0 && rw == 1 && lead) { w <<= 8 * lead; valid -= 8 * lead; }      // bytes before the stream
+                if (valid > bits_left) { valid = (int)bits_left; w = valid ? w & ~(0xffffffffu >> valid) : 0u; }   // bytes after it
+                win |= (u64)w << (32 - have);
+                have += valid; bits_left -= valid;
+            }
+        };
+        auto emit = [&](int32_t v32) {
+            const int slot = (int)(n_out & 3);
+            if (!vec) out[n_out] = v32;
+            else if (slot == 0) o0 = v32; else if (slot == 1) o1 = v32; else if (slot == 2) o2 = v32;
+            else { const v4u q4 = {(uint32_t)o0, (uint32_t)o1, (uint32_t)o2, (uint32_t)v32}; *FRAD_GPTR(v4u, out + n_out - 3) = q4; }
+            ++n_out;
+            if (n_out >= cap) active = false;
+        };
+        while (active) {
+            refill();
+            if (phase == 0 && m == 0 && k < 31 && (win >> 32) != 0) {
+                // the common case in straight-line 32-bit arithmetic: the whole code (z zeros, then z + k + 1 bits) lies in
+                // the top 32 bits of the window
+                const uint32_t top = (uint32_t)(win >> 32);
+                const int z = __builtin_clz(top), nb = z + k + 1, total = z + nb;
+                if (total <= 32 && total <= have) {
+                    const int32_t n = (int32_t)((top << z) >> (32 - nb)) - (int32_t)(1u << k);       // >= 0: the leading bit is 2^(z+k)
+                    emit((n & 1) ? (n + 1) >> 1 : -(n >> 1));
+                    win <<= total; have -= total;
+                    continue;
+                }
+            }
+            if (phase == 0) {                                     // m = index of the first '1' (p1tools.py:68)
+                if (have == 0) { if (bits_left == 0) active = false; break; }      // none left: stop -- or next round
+                if (win == 0) { m += have; have = 0; continue; }
+                const int z = __builtin_clzll(win);               // < have: only the top `have` bits can be set
+                m += z; win = z >= 64 ? 0 : win << z; have -= z;
+                // the codeword is data[:2m + k + 1]: the m zeros just skipped and m + k + 1 more bits -- fewer at the end
+                // of the buffer, where Python's slice is simply shorter
+                want = m + (long long)k + 1;
+                const long long left = (long long)have + bits_left;
+                if (want > left) want = left;
+                val = 0; big = false; phase = 1;
+            }
+            bool starved = false;
             while (want > 0) {
-                r.refill();
+                refill();
+                if (have == 0) { starved = true; break; }         // the rest of this code arrives with the next round
                 int take = want > 32 ? 32 : (int)want;
-                if (take > r.have) take = r.have;
+                if (take > have) take = have;
                 if (val >> (64 - take)) big = true;
-                val = (val << take) | (r.win >> (64 - take));
-                r.drop(take); want -= take;
+                val = (val << take) | (win >> (64 - take));
+                win = take >= 64 ? 0 : win << take; have -= take; want -= take;
             }
+            if (starved) break;
             // n = int(codeword, 2) - 2^k; value = (n + 1) >> 1 if n is odd else -(n >> 1)   (Python integers)
             long long v;
             if (big || k >= 62 || val >= (1ull << 62)) {
@@ -234,8 +302,19 @@ __device__ void decode_stream(const unsigned char* p, long long len, int32_t* __
                 const long long n = (long long)val - (1LL << k);
                 v = (n & 1) ? (n + 1) >> 1 : -(n >> 1);
             }
-            out[n_out++] = sat32(v);
+            emit(sat32(v));
+            phase = 0; m = 0;
         }
+        FRAD_LDS_BARRIER();                                       // rows are rewritten next round
+    }
+    if (vec && (n_out & 3)) {                                 // values parked in registers: write them singly
+        const long long base = n_out & ~3LL; const int cnt = (int)(n_out & 3);
+        out[base] = o0; if (cnt > 1) out[base + 1] = o1; if (cnt > 2) out[base + 2] = o2;
+    }
+    if (vec) {
+        for (; n_out < cap && (n_out & 3); ++n_out) out[n_out] = 0;
+        const v4u z4 = {0, 0, 0, 0};
+        for (; n_out + 4 <= cap; n_out += 4) *FRAD_GPTR(v4u, out + n_out) = z4;
     }
     for (; n_out < cap; ++n_out) out[n_out] = 0;
 }
@@ -243,22 +322,22 @@ __device__ void decode_stream(const unsigned char* p, long long len, int32_t* __
 __global__ void __launch_bounds__(64) k_gol_decode(const unsigned char* __restrict__ bodies, const long long* __restrict__ offsets, long long n_frames,
                                                    long long nq, long long ntq, int32_t* __restrict__ q, int32_t* __restrict__ tq,
                                                    int32_t* __restrict__ status) {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long f = t >> 1; const int which = (int)(t & 1);             // 0: thresholds, 1: coefficients
-    if (f >= n_frames) return;
-    const unsigned char* b = bodies + offsets[f];
-    const long long len = offsets[f + 1] - offsets[f];
-    int32_t* dst = which ? q + f * nq : tq + f * ntq;
-    const long long cap = which ? nq : ntq;
-    if (len < 4) {                                            // no length word: nothing decodable (the host treats it as broken)
-        for (long long i = 0; i < cap; ++i) dst[i] = 0;
-        if (which == 0 && status) status[f] = 1;
-        return;
+    const long long f = (long long)blockIdx.x * 64 + threadIdx.x;
+    const bool live = f < n_frames;                           // spare lanes of the last wave keep the rounds uniform
+    const unsigned char* b = live ? bodies + offsets[f] : bodies;
+    long long len = live ? offsets[f + 1] - offsets[f] : 0;
+    long long tlen = 0;
+    if (live && status) status[f] = len < 4 ? 1 : 0;          // no length word: nothing decodable (the host treats it as broken)
+    if (len >= 4) {
+        tlen = ((long long)b[0] << 24) | ((long long)b[1] << 16) | ((long long)b[2] << 8) | (long long)b[3];
+        if (tlen > len - 4) tlen = len - 4;                   // frad[:thresbytes] past the end: Python slicing clamps
+    } else len = 4;                                           // both streams empty -> zero fill
+    for (int which = 0; which < 2; ++which) {                 // thresholds, then coefficients (one copy of the parser)
+        const unsigned char* sp = which ? b + 4 + tlen : b + 4;
+        const long long sl = which ? len - 4 - tlen : tlen;
+        int32_t* dst = which ? q + (live ? f * nq : 0) : tq + (live ? f * ntq : 0);
+        decode_stream_wave(sp, sl, dst, live ? (which ? nq : ntq) : 0);
     }
-    long long tlen = ((long long)b[0] << 24) | ((long long)b[1] << 16) | ((long long)b[2] << 8) | (long long)b[3];
-    if (tlen > len - 4) tlen = len - 4;                       // frad[:thresbytes] past the end: Python slicing clamps
-    if (which == 0) { decode_stream(b + 4, tlen, dst, cap); if (status) status[f] = 0; }
-    else decode_stream(b + 4 + tlen, len - 4 - tlen, dst, cap);
 }
 
 thread_local int g_gol_hip = 0;
@@ -311,9 +390,9 @@ int frad_p1_golomb_decode(const void* bodies, const int64_t* offsets, int64_t n_
     if (n_frames < 0 || N < 1 || C < 1 || C > 256) return FRAD_E_INVALID;
     if (n_frames == 0) return FRAD_OK;
     if (!bodies || !offsets || !q || !tq) return FRAD_E_INVALID;
-    const long long lanes = 2 * (long long)n_frames, blocks = (lanes + 63) / 64;
+    const long long blocks = ((long long)n_frames + 63) / 64;
     if (blocks > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
-    hipLaunchKernelGGL(k_gol_decode, dim3((unsigned)blocks), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<const unsigned char*>(bodies),
+    hipLaunchKernelGGL(k_gol_decode, dim3((unsigned)blocks), dim3(64), DEC_LDS, static_cast<hipStream_t>(stream), static_cast<const unsigned char*>(bodies),
                        reinterpret_cast<const long long*>(offsets), (long long)n_frames, (long long)N * C, 27LL * C, q, tq, status);
     GOLCHK(hipGetLastError());
     return FRAD_OK;

@@ -79,6 +79,19 @@ class Decoder:
         payloads = [e[0] if e[0] is not None else self._data[e[1]:e[1] + e[2]] for e in entries]
         if profile == 1:
             bits = _P1_DEPTHS[depth_idx]
+            on_device = getattr(self.bridge, "p1_decode_bodies", None)
+            if on_device is not None:
+                # inflate on the host (profile1.py:59), Golomb decode + dequantise + IDCT on the device
+                bodies, bad = [], []
+                for i, frad in enumerate(payloads):
+                    try:
+                        bodies.append(zlib.decompress(frad, wbits=-15))
+                    except Exception:
+                        bodies.append(b""); bad.append(i)            # profile1.py:59-60 -> a frame of zeros
+                pcm = on_device(bodies, fsize, channels, bits, srate)
+                for i in bad:
+                    pcm[i] = 0.0
+                return self._finish_run(pcm, key)
             qs = np.zeros((len(payloads), fsize * channels), np.int32)
             ts = np.zeros((len(payloads), 27 * channels), np.int32)
             bad = []
@@ -97,6 +110,10 @@ class Decoder:
                 pcm[i] = 0.0
         else:
             pcm = self.bridge.lossless_decode(profile, payloads, fsize, channels, _LOSSLESS_DEPTHS[depth_idx], endian)
+        return self._finish_run(pcm, key)
+
+    def _finish_run(self, pcm: np.ndarray, key) -> list:
+        profile, fsize, channels, depth_idx, endian, srate, ratio = key
         if profile in profiles.COMPACT and ratio != 0:
             # Hann cross-fade against the previous frame's tail (decoder.py:28-46) on the device
             L = fsize - fsize * (ratio - 1) // ratio

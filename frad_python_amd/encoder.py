@@ -59,11 +59,16 @@ class Encoder:
         a.srate = compact.get_valid_srate(self.srate) if a.profile in profiles.COMPACT else self.srate
         return a.write(frad)
 
+    @staticmethod
+    def _deflate(body: bytes) -> bytes:
+        co = zlib.compressobj(zlib.Z_DEFAULT_COMPRESSION, zlib.DEFLATED, -15)     # profile1.py:50 wbits=-15
+        return co.compress(body) + co.flush()
+
     def _p1_pack(self, q: np.ndarray, tq: np.ndarray) -> bytes:
+        """host form of the entropy stage, for bridges without a device coder (the CPU-only tests' bridge)"""
         tg = p1tools.exp_golomb_rice_encode(tq)
         fg = p1tools.exp_golomb_rice_encode(q)
-        co = zlib.compressobj(zlib.Z_DEFAULT_COMPRESSION, zlib.DEFLATED, -15)     # profile1.py:50 wbits=-15
-        return co.compress(struct.pack(">I", len(tg)) + tg + fg) + co.flush()
+        return self._deflate(struct.pack(">I", len(tg)) + tg + fg)
 
     def _encode_frames(self, pcm: bytes, n_frames: int, n_eff: int, hop: int, n_valid: int) -> bytes:
         """n_frames frames of n_eff sample-frames, frame i starting i*hop sample-frames into `pcm`."""
@@ -72,6 +77,13 @@ class Encoder:
         if prof == 1:
             bits = self.bit_depth if self.bit_depth in _P1_DEPTHS else 16
             N = compact.get_samples_min_ge(n_eff)
+            on_device = getattr(self.bridge, "p1_encode_bodies", None)
+            if on_device is not None:
+                # quantiser and Exp-Golomb-Rice coder on the device; the host only deflates (profile1.py:50) and frames
+                for body in on_device(pcm, self.pcm_format_name, n_frames, N, C, bits, compact.get_valid_srate(self.srate),
+                                      self.loss_level, hop, n_valid):
+                    out.append(self._emit(self._deflate(body), _P1_DEPTHS.index(bits), n_valid))
+                return b"".join(out)
             q, tq = self.bridge.p1_encode(pcm, self.pcm_format_name, n_frames, N, C, bits, compact.get_valid_srate(self.srate),
                                           self.loss_level, hop, n_valid)
             for i in range(n_frames):

@@ -93,6 +93,26 @@ class EmuBackend:
         self.lib.p1_digital(qq.ctypes.data, tt.ctypes.data, F, N, C, bits, srate, out.ctypes.data)
         return out[:F]
 
+    def golomb_encode(self, q, tq, offset=1):
+        """-> list of per-frame pre-deflate bodies (frad_p1_golomb_encode + frad_rows_compact)"""
+        q, tq = np.ascontiguousarray(q, np.int32), np.ascontiguousarray(tq, np.int32)
+        F, N, C = q.shape
+        stride = self.lib.p1_golomb_bound(N, C)
+        rows = np.full(F * stride + 16, 0xAA, np.uint8); nb = np.zeros(max(F, 1), np.int64)
+        base = rows.ctypes.data + (-rows.ctypes.data) % 16
+        self.lib.p1_golomb_encode(q.ctypes.data, tq.ctypes.data, F, N, C, base, stride, nb.ctypes.data)
+        offs = np.zeros(F + 1, np.int64); out = np.zeros(int(nb[:F].sum()) + 8 + offset, np.uint8)
+        self.lib.rows_compact(base, stride, nb.ctypes.data, F, out.ctypes.data + offset, offs.ctypes.data)     # mis-aligned target
+        return [bytes(out[offset + offs[i]:offset + offs[i + 1]]) for i in range(F)]
+
+    def golomb_decode(self, bodies, N, C):
+        F = len(bodies)
+        offs = np.zeros(F + 1, np.int64); np.cumsum([len(b) for b in bodies], out=offs[1:])
+        buf = np.frombuffer(b"".join(bodies) + b"\0" * 8, np.uint8).copy()
+        q = np.full((max(F, 1), N, C), 7, np.int32); tq = np.full((max(F, 1), 27, C), 7, np.int32); st = np.zeros(max(F, 1), np.int32)
+        self.lib.p1_golomb_decode(buf.ctypes.data, offs.ctypes.data, F, N, C, q.ctypes.data, tq.ctypes.data, st.ctypes.data)
+        return q[:F], tq[:F], st[:F]
+
     def p1_ola(self, frames, ratio, prev_tail=None):
         F, N, C = frames.shape
         cut = N * (ratio - 1) // ratio
@@ -178,6 +198,24 @@ class GpuBackend:
                                     t.from_numpy(np.ascontiguousarray(tq, np.int32)).to(self.dev), N, C, bits, srate)
         t.cuda.synchronize()
         return out.cpu().numpy()
+
+    def golomb_encode(self, q, tq, offset=1):
+        from frad_python_amd import core
+        t = self.torch
+        flat, offsets = core.p1_golomb_encode_batch(t.from_numpy(np.ascontiguousarray(q, np.int32)).to(self.dev),
+                                                    t.from_numpy(np.ascontiguousarray(tq, np.int32)).to(self.dev))
+        t.cuda.synchronize()
+        host, off = flat.cpu().numpy().tobytes(), offsets.cpu().numpy()
+        return [host[off[i]:off[i + 1]] for i in range(q.shape[0])]
+
+    def golomb_decode(self, bodies, N, C):
+        from frad_python_amd import core
+        t = self.torch
+        offs = np.zeros(len(bodies) + 1, np.int64); np.cumsum([len(b) for b in bodies], out=offs[1:])
+        flat = t.from_numpy(np.frombuffer(b"".join(bodies) + b"\0" * 8, np.uint8).copy()).to(self.dev)
+        q, tq, st = core.p1_golomb_decode_batch(flat, t.from_numpy(offs).to(self.dev), N, C)
+        t.cuda.synchronize()
+        return q.cpu().numpy(), tq.cpu().numpy(), st.cpu().numpy()
 
     def p1_ola(self, frames, ratio, prev_tail=None):
         from frad_python_amd import core

@@ -145,3 +145,74 @@ def test_p1_frames_wider_than_a_cu(be, geom, g6):
     dec = be.p1_digital(wq.reshape(1, N, C).astype(np.int32), wt.reshape(1, 27, C).astype(np.int32), N, C, 16, sr)[0]
     ref = g6[f"w_{N}_{C}_dec"]
     assert np.max(np.abs(dec - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Exp-Golomb-Rice stage on the device (p1tools.py:46-74, profile1.py:43-45, 59-64): bit-exact, no tolerance
+# ---------------------------------------------------------------------------------------------------------------------
+def _pad(a, n):
+    out = np.zeros(n, np.int32); out[:a.size] = a
+    return out
+
+
+def test_golomb_bodies_equal_the_reference_frames(be, g4, g6):
+    """The device coder's pre-deflate body == inflate(reference frame) for G4 (3 loss levels x 3 frames) and the wide
+    G6 frames (multi-tile: 10240 / 10240 / 12800 values); decoding the reference's bodies gives its integers back."""
+    import zlib
+    for lv in (0, 10, 20):
+        qs = np.stack([_pad(g4[f"lv{lv}_f{i}_q"], 4096).reshape(2048, 2) for i in range(3)])
+        ts = np.stack([_pad(g4[f"lv{lv}_f{i}_tq"], 54).reshape(27, 2) for i in range(3)])
+        want = [zlib.decompress(g4[f"lv{lv}_f{i}_frad"].tobytes(), wbits=-15) for i in range(3)]
+        assert be.golomb_encode(qs, ts) == want, lv
+        q, tq, st = be.golomb_decode(want, 2048, 2)
+        assert np.array_equal(q, qs) and np.array_equal(tq, ts) and not st.any(), lv
+    for (N, C) in ((10240, 1), (5120, 2), (2560, 5)):
+        q = _pad(g6[f"w_{N}_{C}_q"], N * C).reshape(1, N, C); t = _pad(g6[f"w_{N}_{C}_tq"], 27 * C).reshape(1, 27, C)
+        want = g6[f"w_{N}_{C}_gol"].tobytes()
+        assert be.golomb_encode(q, t) == [want], (N, C)
+        dq, dt, st = be.golomb_decode([want], N, C)
+        assert np.array_equal(dq, q) and np.array_equal(dt, t), (N, C)
+
+
+def test_golomb_known_answers_and_long_vectors(be, g6):
+    """exp_golomb_rice_encode on single vectors (g4_golomb.json, G6 gol_*): coded as the coefficient stream of a frame
+    whose 27 thresholds are zero (that stream is then the 4 bytes 00 ff ff ff e0)."""
+    from conftest import load_json
+    cases = [(np.array(c["data"], np.int64), bytes.fromhex(c["hex"])) for c in load_json("g4_golomb.json") if c["data"]]
+    cases += [(g6[f"gol_{n}_data"], g6[f"gol_{n}_bytes"].tobytes()) for n in ("lap4k", "lap_wide", "sparse", "zeros", "one", "pow2", "big")]
+    tq0 = bytes([0]) + bytes([0xff, 0xff, 0xff, 0xe0])
+    for data, want in cases:
+        n = data.size
+        body = be.golomb_encode(data.astype(np.int32).reshape(1, n, 1), np.zeros((1, 27, 1), np.int32))[0]
+        assert body[:4] == (5).to_bytes(4, "big") and body[4:9] == tq0, data[:8]
+        assert body[9:] == want, (data[:8], body[9:40].hex(), want[:31].hex())
+        q, tq, st = be.golomb_decode([body], n, 1)
+        assert np.array_equal(q.reshape(-1), data) and not tq.any()
+
+
+def test_golomb_random_round_trip_and_decoder_end_conditions(be):
+    rng = np.random.default_rng(77)
+    F, N, C = (3, 640, 2) if be.name == "emu" else (40, 2048, 2)
+    q = np.rint(rng.laplace(0, 5.0, (F, N, C)) * rng.integers(0, 2, (F, N, 1))).astype(np.int32)
+    q[0] = 0; q[1, 5:] = 0                                     # all-zero frame (k = 0), long zero tail
+    tq = rng.integers(0, 40, (F, 27, C)).astype(np.int32)
+    bodies = be.golomb_encode(q, tq)
+    for f in range(F):
+        tg, fg = fo.golomb_encode(tq[f].reshape(-1)), fo.golomb_encode(q[f].reshape(-1))
+        assert bodies[f] == len(tg).to_bytes(4, "big") + tg + fg, f
+    dq, dt, st = be.golomb_decode(bodies, N, C)
+    assert np.array_equal(dq, q) and np.array_equal(dt, tq)
+    # the reference decoder's end conditions (p1tools.py:62-74): truncated bodies, a code cut short by the end of the
+    # buffer, a body shorter than its length word, a threshold length pointing past the end
+    b = bodies[2]
+    cut = [b[:len(b) // 2], b[:len(b) - 1], b[:7], b[:3], b"", (1 << 20).to_bytes(4, "big") + b[4:60], b + b"\x00" * 5]
+    dq, dt, st = be.golomb_decode(cut, N, C)
+    for i, body in enumerate(cut):
+        if len(body) < 4:
+            assert st[i] == 1 and not dq[i].any() and not dt[i].any()
+            continue
+        tl = int.from_bytes(body[:4], "big")
+        wt, wq = fo.golomb_decode(body[4:4 + tl]) if len(body) > 4 else np.array([]), fo.golomb_decode(body[4 + tl:]) if len(body) > 4 + tl else np.array([])
+        wt, wq = np.clip(wt, -2 ** 31, 2 ** 31 - 1)[:27 * C], np.clip(wq, -2 ** 31, 2 ** 31 - 1)[:N * C]
+        assert np.array_equal(dt[i].reshape(-1), _pad(wt.astype(np.int64), 27 * C)), i
+        assert np.array_equal(dq[i].reshape(-1), _pad(wq.astype(np.int64), N * C)), i

@@ -77,6 +77,14 @@ out.append(line("cfg5 p1 quantise (K7)", F * (N * C * 2 + N * C * 4 + 27 * C * 4
 out.append(line("cfg5 p1 dequantise+IDCT (K8)", F * (N * C * 4 + 27 * C * 4 + N * C * 8), timeit(lambda: core.p1_digital_batch(q, tq, N, C, 16, 48000)), F * hop * C))
 dec = core.p1_digital_batch(q, tq, N, C, 16, 48000)
 out.append(line("cfg5 overlap-add", F * (N * C * 8 + hop * C * 8), timeit(lambda: core.p1_overlap_add(dec, 16)), F * hop * C))
+# Exp-Golomb-Rice stage on the device (row 8f #2): bytes = what the coder reads + writes (int32 in, body bytes out)
+flat, offs = core.p1_golomb_encode_batch(q, tq)
+body_total = int(offs[-1].item())
+out.append(line("cfg5 Exp-Golomb encode (+ compaction)", F * (N * C * 4 + 27 * C * 4) + 2 * body_total,
+                timeit(lambda: core.p1_golomb_encode_batch(q, tq)), F * hop * C))
+out.append(line("cfg5 Exp-Golomb decode", F * (N * C * 4 + 27 * C * 4) + body_total,
+                timeit(lambda: core.p1_golomb_decode_batch(flat, offs, N, C)), F * hop * C))
+out[-1]["body_bytes_per_frame"] = round(body_total / F, 1)
 # device-copy microbench (what a plain copy reaches of the nominal 8 TB/s on this box): read + write bytes / time
 for mib in (256, 1024):
     a = torch.empty(mib << 20, dtype=torch.uint8, device=dev); b = torch.empty_like(a)
@@ -108,5 +116,22 @@ out.append({"case": "e2e stream encode, host bytes -> FrAD bytes (60 s stereo s1
             "Gsamples/s": round(S2 / (t1 - t0) / 1e9, 3), "stream_bytes": len(stream)})
 out.append({"case": "e2e stream decode, FrAD bytes -> host float64", "ms": round((t2 - t1) * 1e3, 2),
             "Gsamples/s": round(S2 / (t2 - t1) / 1e9, 3), "frames": int(d.frames)})
+# the same for profile 1 (cfg 5): quantiser + Golomb coder on the device, deflate + ASFH on the host
+host5 = pcm5.cpu().numpy().tobytes()
+best_e, best_d = 1e9, 1e9
+for _ in range(3):
+    t0 = time.perf_counter()
+    enc_s = Encoder(1, 48000, 2, 16, 2048, "s16le"); enc_s.set_overlap_ratio(16); enc_s.set_loss_level(loss)
+    r = enc_s.process(host5); tail_b = enc_s.flush().buf
+    t1 = time.perf_counter()
+    stream5 = r.buf + tail_b
+    t1b = time.perf_counter()
+    dec_s = Decoder()
+    d5 = dec_s.process(stream5); tail = dec_s.flush()
+    t2 = time.perf_counter()
+    best_e, best_d = min(best_e, t1 - t0), min(best_d, t2 - t1b)
+out.append({"case": "e2e stream encode, profile 1 (60 s stereo s16, N=2048, overlap 16, loss level 20)", "ms": round(best_e * 1e3, 2),
+            "Gsamples/s": round(S2 / best_e / 1e9, 4), "stream_bytes": len(stream5)})
+out.append({"case": "e2e stream decode, profile 1", "ms": round(best_d * 1e3, 2), "Gsamples/s": round(S2 / best_d / 1e9, 4), "frames": int(d5.frames)})
 for o_ in out:
     print(json.dumps(o_))
