@@ -43,8 +43,25 @@ SYMBOLS = {
     "frad_p1_golomb_encode": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
     "frad_rows_compact": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "frad_p1_golomb_decode": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "frad_from_f64": (c_int, [c_void_p, c_int64, c_int32, c_uint32, c_void_p, c_void_p]),
+    "frad_p0_digital_pcm": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_uint32, c_int32, c_void_p, c_void_p]),
+    "frad_p4_digital_pcm": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_uint32, c_int32, c_void_p, c_void_p]),
+    "frad_p1_digital_pcm": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_uint32, c_void_p, c_void_p]),
+    "frad_asfh_scan": (c_int64, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "frad_bench_copy": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
 }
+
+
+# mirror of `frad_frame_info` (include/frad_hip.h)
+def _frame_info_dtype():
+    import numpy as np
+    return np.dtype([("header_off", "<i8"), ("payload_off", "<i8"), ("payload_bytes", "<i8"), ("profile", "<i4"), ("ecc", "<i4"),
+                     ("little_endian", "<i4"), ("depth_idx", "<i4"), ("channels", "<i4"), ("srate", "<i4"), ("fsize", "<i4"),
+                     ("overlap_ratio", "<i4"), ("ecc_dsize", "<i4"), ("ecc_codesize", "<i4"), ("force_flush", "<i4"), ("crc", "<u4")])
+
+
+FRAME_INFO_DTYPE = _frame_info_dtype()
+assert FRAME_INFO_DTYPE.itemsize == 72
 
 
 class FradError(RuntimeError):
@@ -124,6 +141,35 @@ class FradLib:
 
     def p1_golomb_decode(self, bodies, offsets, n_frames, N, C, q, tq, status, stream=0):
         self._check(self.dll.frad_p1_golomb_decode(bodies, offsets, n_frames, N, C, q, tq, status, stream))
+
+    def from_f64(self, pcm, n_values, out_dtype, out, stream=0, flags=FRAD_RAW_BE_INTS):
+        self._check(self.dll.frad_from_f64(pcm, n_values, out_dtype, flags, out, stream))
+
+    def p0_digital_pcm(self, payload, payload_stride, n_frames, N, C, bits, flags, out_dtype, out, stream=0):
+        self._check(self.dll.frad_p0_digital_pcm(payload, payload_stride, n_frames, N, C, bits, flags, out_dtype, out, stream))
+
+    def p4_digital_pcm(self, payload, payload_stride, n_frames, N, C, bits, flags, out_dtype, out, stream=0):
+        self._check(self.dll.frad_p4_digital_pcm(payload, payload_stride, n_frames, N, C, bits, flags, out_dtype, out, stream))
+
+    def p1_digital_pcm(self, q, tq, n_frames, N, C, bits, srate, out_dtype, out, stream=0, flags=FRAD_RAW_BE_INTS):
+        self._check(self.dll.frad_p1_digital_pcm(q, tq, n_frames, N, C, bits, srate, out_dtype, flags, out, stream))
+
+    def asfh_scan(self, data, start: int = 0, max_frames: int = 0):
+        """frad_asfh_scan over a bytes-like object -> (numpy structured table, next_pos, stop_reason)"""
+        import numpy as np
+        view = memoryview(data)
+        n = view.nbytes
+        cap = max_frames or max(16, (n - start) // 9 + 1)
+        cap = min(cap, 1 << 22)
+        table = np.zeros(cap, FRAME_INFO_DTYPE)
+        nxt, why = ctypes.c_int64(0), ctypes.c_int32(0)
+        buf = (ctypes.c_char * n).from_buffer_copy(view) if view.readonly and not isinstance(data, (bytes, bytearray)) else None
+        ptr = ctypes.cast(ctypes.c_char_p(data), c_void_p) if isinstance(data, bytes) else \
+            ctypes.addressof((ctypes.c_char * n).from_buffer(data)) if buf is None else ctypes.addressof(buf)
+        rows = self.dll.frad_asfh_scan(ptr, n, start, table.ctypes.data, cap, ctypes.byref(nxt), ctypes.byref(why))
+        if rows < 0:
+            self._check(int(rows))
+        return table[:rows], int(nxt.value), int(why.value)
 
     def bench_copy(self, src, dst, nbytes, stream=0):
         self._check(self.dll.frad_bench_copy(src, dst, nbytes, stream))

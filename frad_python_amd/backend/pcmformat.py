@@ -59,3 +59,18 @@ def itemsize_of(code: int) -> int:
 
 
 FORMAT_NAMES = tuple(_FORMATS)
+
+
+def from_f64(pcm: np.ndarray, fmt) -> np.ndarray:
+    """Host form of the decoder's output conversion, ``from_f64(pcm, fmt).astype(fmt)`` as the reference's caller
+    applies it (src/libfrad/backend/pcmformat.py:49-62, src/decoder.py:23): floats are cast, native-order integers are
+    scaled by 2^(w-1) (unsigned: after adding 1) and truncated by ``astype``; big-endian integer formats are not
+    recognised by the reference's dtype comparison, so their samples are truncated unscaled.  The device form is
+    ``frad_from_f64`` (csrc/frad_epilogue.hip); this one serves the decoder's rare host-side paths."""
+    dt = ff_format_to_numpy_type(fmt) if isinstance(fmt, str) else np.dtype(fmt)
+    x = np.asarray(pcm, np.float64)
+    if dt.kind in "iu" and dt.isnative:
+        w = 8 * dt.itemsize
+        x = (x + 1.0 if dt.kind == "u" else x) * float(2 ** (w - 1))
+    with np.errstate(all="ignore"):
+        return x.astype(dt)

@@ -20,6 +20,7 @@ class HipBridge:
             raise RuntimeError("the FrAD transform core needs an MI355X (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
         self.torch, self.core = torch, core
+        self.scan_lib = core._lib.load()                      # frad_asfh_scan: the decoder's native header scanner
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
 
     def _up(self, data: bytes):
@@ -80,7 +81,16 @@ class HipBridge:
         stream[:, 28:32] = crc.view(t.uint8).view(n_frames, 4).flip(1)       # big-endian, as int.to_bytes(4, "big")
         return self._down_bytes(stream)
 
-    def lossless_decode_strided(self, profile, region, n_frames, stride, nbytes, N, C, bits, little_endian) -> np.ndarray:
+    def _down_array(self, dev, dtype, shape) -> np.ndarray:
+        """device tensor -> numpy array backed by a pinned host block of its own (torch's caching host allocator hands
+        the block out again once the array is gone): one DMA, no pageable bounce, no second host copy"""
+        t = self.torch
+        host = t.empty(dev.numel() * dev.element_size(), dtype=t.uint8, pin_memory=True)
+        host.copy_(dev.reshape(-1).view(t.uint8), non_blocking=True)
+        t.cuda.current_stream(self.device).synchronize()
+        return host.numpy().view(dtype).reshape(shape)
+
+    def lossless_decode_strided(self, profile, region, n_frames, stride, nbytes, N, C, bits, little_endian, out_format=None) -> np.ndarray:
         """Frames that sit equally spaced in the stream (``region`` = first payload byte .. last payload byte, a
         read-only buffer): one H2D copy of the region, headers and all, and the kernels step over it with
         ``payload_stride = stride``; no per-frame host copies."""
@@ -91,7 +101,12 @@ class HipBridge:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")                   # read-only buffer: it is only copied to the device
             dev = t.frombuffer(region, dtype=t.uint8).to(self.device)
-        return self.core.digital_batch(profile, dev, n_frames, N, C, bits, little_endian, payload_stride=stride).cpu().numpy()
+        if out_format is not None:                            # narrowed on the device: 2-4x fewer bytes over PCIe
+            from .backend.pcmformat import ff_format_to_numpy_type
+            out = self.core.digital_batch(profile, dev, n_frames, N, C, bits, little_endian, payload_stride=stride, out_format=out_format)
+            return self._down_array(out, ff_format_to_numpy_type(out_format), (n_frames, N, C))
+        out = self.core.digital_batch(profile, dev, n_frames, N, C, bits, little_endian, payload_stride=stride)
+        return self._down_array(out, np.float64, (n_frames, N, C))
 
     def lossless_decode(self, profile, payloads: list, N, C, bits, little_endian) -> np.ndarray:
         n = len(payloads)

@@ -157,10 +157,32 @@ def crc32_frames(payload: torch.Tensor, nbytes: int) -> torch.Tensor:
     return out
 
 
+def _pcm_out_tensor(fmt: str, shape, device) -> torch.Tensor:
+    """uint8 storage for `shape` elements of PCM format `fmt` (torch has no big-endian or unsigned 16/32/64 dtypes)"""
+    n = 1
+    for d in shape:
+        n *= d
+    return torch.empty(n * itemsize_of(pcm_dtype_code(fmt)), dtype=torch.uint8, device=device)
+
+
+def from_f64(pcm: torch.Tensor, out_format: str, *, raw_be_ints: bool = True) -> torch.Tensor:
+    """``from_f64(pcm, fmt).astype(fmt)`` as the reference's caller applies it to decoded blocks (pcmformat.py:49-62,
+    src/decoder.py:23): float64 tensor -> the bytes of PCM format ``out_format`` (uint8 tensor)."""
+    _require_cuda(pcm, "pcm")
+    if pcm.dtype != torch.float64 or not pcm.is_contiguous():
+        raise TypeError("pcm must be contiguous float64")
+    out = _pcm_out_tensor(out_format, pcm.shape, pcm.device)
+    with torch.cuda.device(pcm.device):
+        _lib.load().from_f64(pcm.data_ptr(), pcm.numel(), pcm_dtype_code(out_format), out.data_ptr(), _stream_ptr(),
+                             int(raw_be_ints) * _lib.FRAD_RAW_BE_INTS)
+    return out
+
+
 def digital_batch(profile: int, payload: torch.Tensor, n_frames: int, N: int, C: int, bits: int,
                   little_endian: bool = False, *, payload_stride: int | None = None,
-                  out: torch.Tensor | None = None) -> torch.Tensor:
-    """Profile 0 / 4 ``digital`` over a batch: uint8 payload rows -> float64 [n_frames, N, C]."""
+                  out: torch.Tensor | None = None, out_format: str | None = None) -> torch.Tensor:
+    """Profile 0 / 4 ``digital`` over a batch: uint8 payload rows -> float64 [n_frames, N, C]; with ``out_format`` the
+    samples leave the device already narrowed to that PCM format (uint8 tensor of its bytes, see ``from_f64``)."""
     _require_cuda(payload, "payload")
     lib = _lib.load()
     nbytes = lib.payload_bytes(N, C, bits)
@@ -168,9 +190,17 @@ def digital_batch(profile: int, payload: torch.Tensor, n_frames: int, N: int, C:
         payload_stride = payload.stride(0) if payload.dim() == 2 else nbytes
     if payload.numel() * payload.element_size() < ((n_frames - 1) * payload_stride + nbytes if n_frames else 0):
         raise ValueError("payload tensor is smaller than n_frames frames")
+    flags = int(little_endian) * _lib.FRAD_LITTLE_ENDIAN
+    if out_format is not None:
+        flags |= _lib.FRAD_RAW_BE_INTS                          # the reference's from_f64 does not recognise big-endian ints
+        if out is None:
+            out = _pcm_out_tensor(out_format, (n_frames, N, C), payload.device)
+        fn = lib.p4_digital_pcm if profile == 4 else lib.p0_digital_pcm
+        with torch.cuda.device(payload.device):
+            fn(payload.data_ptr(), payload_stride, n_frames, N, C, bits, flags, pcm_dtype_code(out_format), out.data_ptr(), _stream_ptr())
+        return out
     if out is None:
         out = torch.empty((n_frames, N, C), dtype=torch.float64, device=payload.device)
-    flags = int(little_endian) * _lib.FRAD_LITTLE_ENDIAN
     fn = lib.p4_digital if profile == 4 else lib.p0_digital
     with torch.cuda.device(payload.device):
         fn(payload.data_ptr(), payload_stride, n_frames, N, C, bits, flags, out.data_ptr(), _stream_ptr())

@@ -1,0 +1,269 @@
+// frad_epilogue.hip -- the decoder's output conversion (from_f64) and the native frame-header scan.
+//
+//   from_f64          backend/pcmformat.py:49-62, applied by the reference's caller right after every decode
+//                     (src/decoder.py:23: from_f64(pcm, fmt).astype(fmt)): floats are cast (round to nearest even),
+//                     integers are scaled by 2^(w-1) -- unsigned ones after adding 1 -- and TRUNCATED by numpy's astype.
+//                     Out-of-range samples (a lossy decode overshoots +-1 now and then) are undefined in C; what numpy
+//                     does on x86-64 is what cvttsd2si does, and that is reproduced here: 8/16-bit targets take the low
+//                     bits of the 32-bit conversion, 32-bit unsigned the low half of the 64-bit one, an overflowing
+//                     conversion yields the "integer indefinite" 0x80..0 (NaN too).
+//   k_from_f64        float64 [n] -> any of the 20 PCM formats; fused into the profile-4 unpack (k_p4_unpack_pcm).
+//   frad_asfh_scan    host code: walks a FrAD byte stream once and fills a table of frames (tools/asfh.py:98-134,
+//                     decoder.py:82-106) so that the Python decoder no longer parses headers frame by frame.
+#include "frad_launch.hpp"
+#include "../../include/frad_hip.h"
+
+#include <cstring>
+
+namespace frad {
+namespace {
+
+__device__ __forceinline__ int32_t x86_cvtt32(double v) {      // cvttsd2si r32
+    return (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : (int32_t)0x80000000u;
+}
+__device__ __forceinline__ long long x86_cvtt64(double v) {    // cvttsd2si r64
+    return (v >= -9223372036854775808.0 && v < 9223372036854775808.0) ? (long long)v : (long long)0x8000000000000000ull;
+}
+
+// one float64 sample -> the element's bytes (little-endian in the returned word; `be` formats are swapped by the caller)
+// `raw`: the reference's big-endian-integer quirk on the way out -- pcm_format == np.int16 is False for '>i2', so
+// from_f64 returns the float64 samples unscaled and the caller's .astype(fmt) truncates those (FRAD_RAW_BE_INTS)
+template <int KIND, int LGS>
+__device__ __forceinline__ u64 from_f64_bits(double x, bool raw) {
+    if constexpr (KIND == 2) {
+        if constexpr (LGS == 1) return f64_to_f16_bits(x);
+        else if constexpr (LGS == 2) return f2u((float)x);
+        else return d2u(x);
+    } else {
+        constexpr int w = 8 << LGS;
+        const double scale = u2d((u64)(1023 + (w - 1)) << 52);          // 2^(w-1), exact
+        const double v = raw ? x : (KIND == 0 ? x + 1.0 : x) * scale;
+        if constexpr (LGS <= 1) return (u64)((uint32_t)x86_cvtt32(v) & ((1u << w) - 1u));
+        else if constexpr (LGS == 2) return KIND == 1 ? (u64)(uint32_t)x86_cvtt32(v) : (u64)(uint32_t)x86_cvtt64(v);
+        else {
+            if constexpr (KIND == 1) return (u64)x86_cvtt64(v);
+            else return v >= 9223372036854775808.0 ? (u64)x86_cvtt64(v - 9223372036854775808.0) + 0x8000000000000000ull : (u64)x86_cvtt64(v);
+        }
+    }
+}
+template <int LGS> __device__ __forceinline__ u64 swap_elem(u64 b) {
+    if constexpr (LGS == 1) return bswap16((uint32_t)b);
+    else if constexpr (LGS == 2) return bswap32((uint32_t)b);
+    else if constexpr (LGS == 3) return bswap64(b);
+    else return b;
+}
+template <int LGS> __device__ __forceinline__ void store_elem(unsigned char* p, u64 b) {
+    if constexpr (LGS == 0) *FRAD_GPTR(unsigned char, p) = (unsigned char)b;
+    else if constexpr (LGS == 1) *FRAD_GPTR(unsigned short, p) = (unsigned short)b;
+    else if constexpr (LGS == 2) *FRAD_GPTR(uint32_t, p) = (uint32_t)b;
+    else *FRAD_GPTR(u64, p) = b;
+}
+
+// SRC 0: float64 samples at `in`; SRC 1: profile-4 payload rows (unpack + scrub fused, profile4.py:43-63)
+template <int KIND, int LGS, int SRC>
+__global__ void __launch_bounds__(256) k_from_f64(const unsigned char* __restrict__ in, unsigned char* __restrict__ out, long long n, int be, Geom g) {
+    constexpr int EPT = 16 >> LGS;                             // elements per thread: one 16-byte store when aligned
+    const long long NC = (long long)g.N * g.C;
+    const bool le = g.le && (g.bits % 8 == 0);
+    const bool vec = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    for (long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * EPT; i0 < n; i0 += (long long)gridDim.x * blockDim.x * EPT) {
+        u64 b[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const long long i = i0 + e;
+            double x = 0.0;
+            if (i < n) {
+                if constexpr (SRC == 0) x = reinterpret_cast<const double*>(in)[i];
+                else { const long long f = i / NC; x = code_to_f64(code_from_bytes(in + f * g.payload_stride, i - f * NC, g.bits, le), g.bits); }
+            }
+            b[e] = from_f64_bits<KIND, LGS>(x, g.raw_be != 0 && be);
+            if (be) b[e] = swap_elem<LGS>(b[e]);
+        }
+        if (vec && i0 + EPT <= n) {
+            v4u q = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                if constexpr (LGS == 3) { q[2 * e] = (uint32_t)b[e]; q[2 * e + 1] = (uint32_t)(b[e] >> 32); }
+                else if constexpr (LGS == 2) q[e] = (uint32_t)b[e];
+                else if constexpr (LGS == 1) q[e >> 1] |= (uint32_t)b[e] << (16 * (e & 1));
+                else q[e >> 2] |= (uint32_t)b[e] << (8 * (e & 3));
+            }
+            FRAD_NT_STORE(q, FRAD_GPTR(v4u, out + (i0 << LGS)));
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) if (i0 + e < n) store_elem<LGS>(out + ((i0 + e) << LGS), b[e]);
+        }
+    }
+}
+
+template <int SRC>
+int launch_from_f64(int dtype, const unsigned char* in, unsigned char* out, long long n, const Geom& g, hipStream_t s) {
+    const int kind = dtype >> 3, lg = (dtype >> 1) & 3, be = dtype & 1;
+    const long long per_block = 256LL * (16 >> lg);
+    long long blocks = (n + per_block - 1) / per_block;
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) blocks = 1;
+    const dim3 grid((unsigned)blocks), blk(256);
+#define GO(K, L) hipLaunchKernelGGL((k_from_f64<K, L, SRC>), grid, blk, 0, s, in, out, n, be, g)
+    switch (kind * 4 + lg) {
+        case 0: GO(0, 0); break; case 1: GO(0, 1); break; case 2: GO(0, 2); break; case 3: GO(0, 3); break;
+        case 4: GO(1, 0); break; case 5: GO(1, 1); break; case 6: GO(1, 2); break; case 7: GO(1, 3); break;
+        case 9: GO(2, 1); break; case 10: GO(2, 2); break; case 11: GO(2, 3); break;
+        default: return FRAD_E_INVALID;
+    }
+#undef GO
+    return FRAD_OK;
+}
+
+bool valid_out_dtype(int d) {
+    if (d < 0 || d > 23) return false;
+    const int kind = d >> 3, lg = (d >> 1) & 3, be = d & 1;
+    return !(kind == 2 && lg == 0) && !(lg == 0 && be);
+}
+
+thread_local int g_epi_hip = 0;
+#define EPICHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_epi_hip = (int)e_; return FRAD_E_HIP; } } while (0)
+
+struct Scratch {                                               // stream-ordered float64 staging for the two-pass decodes
+    hipStream_t s; void* p = nullptr;
+    explicit Scratch(hipStream_t st) : s(st) {}
+    ~Scratch() { if (p) (void)hipFreeAsync(p, s); }
+};
+
+}  // namespace
+}  // namespace frad
+
+using namespace frad;
+
+extern "C" {
+
+int frad_from_f64(const double* pcm, int64_t n_values, int32_t out_dtype, uint32_t flags, void* out, void* stream) {
+    if (n_values < 0 || !valid_out_dtype(out_dtype)) return FRAD_E_INVALID;
+    if (n_values == 0) return FRAD_OK;
+    if (!pcm || !out) return FRAD_E_INVALID;
+    Geom g{}; g.N = 1; g.C = 1; g.bits = 64; g.raw_be = (flags & FRAD_RAW_BE_INTS) ? 1 : 0;
+    const int rc = launch_from_f64<0>(out_dtype, reinterpret_cast<const unsigned char*>(pcm), static_cast<unsigned char*>(out), n_values, g,
+                                      static_cast<hipStream_t>(stream));
+    if (rc != FRAD_OK) return rc;
+    EPICHK(hipGetLastError());
+    return FRAD_OK;
+}
+
+int frad_p4_digital_pcm(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C, int32_t bits,
+                        uint32_t flags, int32_t out_dtype, void* pcm_out, void* stream) {
+    if (n_frames < 0 || N < 1 || C < 1 || C > 256 || !valid_out_dtype(out_dtype)) return FRAD_E_INVALID;
+    if (!(bits == 12 || bits == 16 || bits == 24 || bits == 32 || bits == 48 || bits == 64)) return FRAD_E_INVALID;
+    if (n_frames == 0) return FRAD_OK;
+    if (!payload || !pcm_out || payload_stride < (int64_t)frad_payload_bytes(N, C, bits)) return FRAD_E_INVALID;
+    Geom g{}; g.n_frames = n_frames; g.N = N; g.C = C; g.bits = bits; g.le = (flags & FRAD_LITTLE_ENDIAN) ? 1 : 0; g.payload_stride = payload_stride;
+    g.raw_be = (flags & FRAD_RAW_BE_INTS) ? 1 : 0;
+    const int rc = launch_from_f64<1>(out_dtype, static_cast<const unsigned char*>(payload), static_cast<unsigned char*>(pcm_out),
+                                      (long long)n_frames * N * C, g, static_cast<hipStream_t>(stream));
+    if (rc != FRAD_OK) return rc;
+    EPICHK(hipGetLastError());
+    return FRAD_OK;
+}
+
+// profile 0 / 1: the transform kernels write float64; the narrowing pass follows on the same stream (the staging buffer
+// is stream-ordered scratch).  TODO(next): fuse the cast into the N = 2048 wave kernel's output stage.
+int frad_p0_digital_pcm(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C, int32_t bits,
+                        uint32_t flags, int32_t out_dtype, void* pcm_out, void* stream) {
+    if (!valid_out_dtype(out_dtype)) return FRAD_E_INVALID;
+    if (out_dtype == FRAD_PCM_F64LE) return frad_p0_digital(payload, payload_stride, n_frames, N, C, bits, flags, static_cast<double*>(pcm_out), stream);
+    if (n_frames < 0 || N < 1 || C < 1) return FRAD_E_INVALID;
+    if (n_frames == 0) return FRAD_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scratch ws(s);
+    const size_t n = (size_t)n_frames * N * C;
+    if (hipMallocAsync(&ws.p, n * 8, s) != hipSuccess) return FRAD_E_NOMEM;
+    int rc = frad_p0_digital(payload, payload_stride, n_frames, N, C, bits, flags, static_cast<double*>(ws.p), stream);
+    if (rc != FRAD_OK) return rc;
+    return frad_from_f64(static_cast<const double*>(ws.p), (int64_t)n, out_dtype, flags, pcm_out, stream);
+}
+
+int frad_p1_digital_pcm(const int32_t* q, const int32_t* tq, int64_t n_frames, int32_t N, int32_t C, int32_t bits, int32_t srate,
+                        int32_t out_dtype, uint32_t flags, void* pcm_out, void* stream) {
+    if (!valid_out_dtype(out_dtype)) return FRAD_E_INVALID;
+    if (out_dtype == FRAD_PCM_F64LE) return frad_p1_digital(q, tq, n_frames, N, C, bits, srate, static_cast<double*>(pcm_out), stream);
+    if (n_frames < 0 || N < 1 || C < 1) return FRAD_E_INVALID;
+    if (n_frames == 0) return FRAD_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Scratch ws(s);
+    const size_t n = (size_t)n_frames * N * C;
+    if (hipMallocAsync(&ws.p, n * 8, s) != hipSuccess) return FRAD_E_NOMEM;
+    int rc = frad_p1_digital(q, tq, n_frames, N, C, bits, srate, static_cast<double*>(ws.p), stream);
+    if (rc != FRAD_OK) return rc;
+    return frad_from_f64(static_cast<const double*>(ws.p), (int64_t)n, out_dtype, flags, pcm_out, stream);
+}
+
+// ---- native frame-header scan (host code, no device involved) --------------------------------------------------------
+static inline uint32_t be32(const unsigned char* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+int64_t frad_asfh_scan(const void* stream_bytes, int64_t nbytes, int64_t start, frad_frame_info* frames, int64_t max_frames,
+                       int64_t* next_pos, int32_t* stop_reason) {
+    static const unsigned char SIGN[4] = {0xff, 0xd0, 0xd2, 0x98};                     // common.py FRM_SIGN
+    static const int SRATES[12] = {96000, 88200, 64000, 48000, 44100, 32000, 24000, 22050, 16000, 12000, 11025, 8000};
+    if (!stream_bytes || nbytes < 0 || start < 0 || max_frames < 0 || (!frames && max_frames > 0) || !next_pos || !stop_reason) return FRAD_E_INVALID;
+    const unsigned char* d = static_cast<const unsigned char*>(stream_bytes);
+    int64_t pos = start, n = 0;
+    *stop_reason = FRAD_SCAN_END;
+    while (n < max_frames) {
+        // next signature (decoder.py:82-90); keep the last three bytes when none is found: a signature may be split
+        const unsigned char* at = nullptr;
+        for (int64_t p = pos; p + 4 <= nbytes; ) {
+            const void* hit = memchr(d + p, 0xff, (size_t)(nbytes - 3 - p));
+            if (!hit) break;
+            const unsigned char* h = static_cast<const unsigned char*>(hit);
+            if (memcmp(h, SIGN, 4) == 0) { at = h; break; }
+            p = (h - d) + 1;
+        }
+        if (!at) { pos = nbytes - 3 > pos ? nbytes - 3 : pos; *stop_reason = FRAD_SCAN_END; break; }
+        const int64_t h0 = at - d;
+        frad_frame_info fi; memset(&fi, 0, sizeof fi);
+        fi.header_off = h0;
+        if (nbytes - h0 < 9) { pos = h0; *stop_reason = FRAD_SCAN_PARTIAL_HEADER; break; }
+        uint64_t len = be32(d + h0 + 4);
+        const unsigned pfb = d[h0 + 8];
+        fi.profile = (int32_t)(pfb >> 5); fi.ecc = (pfb >> 4) & 1; fi.little_endian = (pfb >> 3) & 1; fi.depth_idx = pfb & 7;
+        const bool compact_prof = fi.profile == 1 || fi.profile == 2;
+        int64_t hlen = compact_prof ? 12 : 32;
+        if (nbytes - h0 < hlen) { pos = h0; *stop_reason = FRAD_SCAN_PARTIAL_HEADER; break; }
+        if (compact_prof) {
+            const unsigned css = ((unsigned)d[h0 + 9] << 8) | d[h0 + 10];
+            fi.channels = (int32_t)(css >> 10) + 1;
+            const unsigned si = (css >> 6) & 0xF;
+            fi.srate = si < 12 ? SRATES[si] : 0;
+            const unsigned fidx = (css >> 1) & 0x1F;
+            fi.fsize = (int32_t)((fidx & 3) == 0 ? 128 : (fidx & 3) == 1 ? 160 : (fidx & 3) == 2 ? 192 : 224) << (fidx >> 2);
+            fi.force_flush = (int32_t)(css & 1);
+            if (fi.force_flush) {
+                fi.payload_off = h0 + hlen; fi.payload_bytes = 0;
+                frames[n++] = fi; pos = h0 + hlen;
+                continue;
+            }
+            fi.overlap_ratio = d[h0 + 11] ? d[h0 + 11] + 1 : 0;
+            if (fi.ecc) {
+                hlen = 16;
+                if (nbytes - h0 < hlen) { pos = h0; *stop_reason = FRAD_SCAN_PARTIAL_HEADER; break; }
+                fi.ecc_dsize = d[h0 + 12]; fi.ecc_codesize = d[h0 + 13]; fi.crc = ((uint32_t)d[h0 + 14] << 8) | d[h0 + 15];
+            }
+        } else {
+            fi.channels = (int32_t)d[h0 + 9] + 1; fi.ecc_dsize = d[h0 + 10]; fi.ecc_codesize = d[h0 + 11];
+            fi.srate = (int32_t)be32(d + h0 + 12); fi.fsize = (int32_t)be32(d + h0 + 24); fi.crc = be32(d + h0 + 28);
+        }
+        if (len == 0xFFFFFFFFull) {                            // 64-bit length extension (asfh.py:128-132)
+            if (nbytes - h0 < hlen + 8) { pos = h0; *stop_reason = FRAD_SCAN_PARTIAL_HEADER; break; }
+            len = ((uint64_t)be32(d + h0 + hlen) << 32) | be32(d + h0 + hlen + 4);
+            hlen += 8;
+        }
+        fi.payload_off = h0 + hlen; fi.payload_bytes = (int64_t)len;
+        if ((uint64_t)(nbytes - fi.payload_off) < len) { pos = h0; *stop_reason = FRAD_SCAN_PARTIAL_PAYLOAD; break; }
+        frames[n++] = fi;
+        pos = fi.payload_off + (int64_t)len;
+        if (n == max_frames) { *stop_reason = FRAD_SCAN_TABLE_FULL; break; }
+    }
+    *next_pos = pos;
+    return n;
+}
+
+}  // extern "C"

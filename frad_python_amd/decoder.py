@@ -14,6 +14,7 @@ from . import common
 from .fourier import profiles
 from .fourier.tools import p1tools
 from .tools.asfh import ASFH
+from .backend.pcmformat import from_f64
 
 _LOSSLESS_DEPTHS = (12, 16, 24, 32, 48, 64)
 _P1_DEPTHS = (8, 12, 16, 24, 32, 48, 64)
@@ -22,7 +23,9 @@ _P1_DEPTHS = (8, 12, 16, 24, 32, 48, 64)
 class DecodeResult:
     def __init__(self, pcm: list, srate: int, frames: int, crit: bool):
         pcm = [p for p in pcm if p.size]
-        self.pcm = np.concatenate(pcm) if pcm else np.array([])
+        self.pcm = (pcm[0] if len(pcm) == 1 else np.concatenate(pcm)) if pcm else np.array([])
+        if pcm and self.pcm.dtype != pcm[0].dtype:             # concatenate drops a big-endian byte order (out_format)
+            self.pcm = self.pcm.astype(pcm[0].dtype)
         self.srate = srate
         self.frames = frames
         self.crit = crit
@@ -35,7 +38,11 @@ def _strip_ecc(frad: bytes, dsize: int, codesize: int) -> bytes:
 
 
 class Decoder:
-    def __init__(self, fix_error: bool = False, *, bridge=None):
+    def __init__(self, fix_error: bool = False, *, bridge=None, out_format: str | None = None):
+        """``out_format`` (extension): a PCM format name; DecodeResult.pcm then holds ``from_f64(pcm, fmt).astype(fmt)``
+        -- what the reference's caller computes right after every process() (src/decoder.py:23) -- done on the device
+        for the bulk path, so that 2-8 bytes per sample cross PCIe instead of 8."""
+        self.out_format = out_format
         if fix_error:
             raise NotImplementedError("Reed-Solomon repair is host-side and needs the third-party reedsolo module; "
                                       "it is outside the MI355X transform core")
@@ -63,6 +70,12 @@ class Decoder:
 
     # ------------------------------------------------------------------ batched decode of one run of frames
     def _decode_run(self, key, entries: list) -> list:
+        pieces = self._decode_run_f64(key, entries)
+        if self.out_format is not None:                        # whatever did not come narrowed from the device
+            pieces = [from_f64(p, self.out_format) if p.dtype == np.float64 else p for p in pieces]
+        return pieces
+
+    def _decode_run_f64(self, key, entries: list) -> list:
         """entries: (payload bytes or None, offset in self._data, length) per frame of the run"""
         profile, fsize, channels, depth_idx, endian, srate, ratio = key
         strided = getattr(self.bridge, "lossless_decode_strided", None)
@@ -71,11 +84,15 @@ class Decoder:
             if step > 0 and all(entries[i + 1][1] - entries[i][1] == step for i in range(len(entries) - 1)):
                 first, nb = entries[0][1], entries[0][2]
                 region = memoryview(self._data)[first:entries[-1][1] + nb]
-                pcm = strided(profile, region, len(entries), step, nb, fsize, channels, _LOSSLESS_DEPTHS[depth_idx], endian)
+                narrow = self.out_format if not self.overlap_fragment.size else None
+                if narrow is not None:
+                    pcm = strided(profile, region, len(entries), step, nb, fsize, channels, _LOSSLESS_DEPTHS[depth_idx], endian, out_format=narrow)
+                else:
+                    pcm = strided(profile, region, len(entries), step, nb, fsize, channels, _LOSSLESS_DEPTHS[depth_idx], endian)
                 if pcm is not None:
                     if self.overlap_fragment.size:
                         return self._overlap_host(pcm, key)
-                    return list(pcm)
+                    return [pcm.reshape(-1, channels)]             # one piece: no per-frame list, no concatenate
         payloads = [e[0] if e[0] is not None else self._data[e[1]:e[1] + e[2]] for e in entries]
         if profile == 1:
             bits = _P1_DEPTHS[depth_idx]
@@ -198,11 +215,18 @@ class Decoder:
 
     def process(self, stream: bytes) -> DecodeResult:
         """Parse as the reference does (decoder.py:51-108) but decode runs of like frames in one launch each."""
-        self._data, self._pos = self.buffer + stream, 0
+        self._data, self._pos = (self.buffer + stream) if self.buffer else stream, 0
         try:
-            return self._process(len(stream) == 0)
+            res = self._process(len(stream) == 0)
         finally:
             self.buffer, self._data, self._pos = self._data[self._pos:], b"", 0
+        return self._narrow(res)
+
+    def _narrow(self, res: DecodeResult) -> DecodeResult:
+        """out_format: pieces that did not come narrowed from the device (float64) are converted here"""
+        if self.out_format is not None and res.pcm.dtype == np.float64 and res.pcm.size:
+            res.pcm = from_f64(res.pcm, self.out_format)
+        return res
 
     def _process(self, stream_was_empty: bool) -> DecodeResult:
         pieces, frames = [], 0
@@ -226,6 +250,23 @@ class Decoder:
                 run.append(frad)
                 frames += 1
                 continue
+            if not self.asfh.buffer and self._scan is not None:
+                # steady state (no half-read header carried over): the native scanner (frad_asfh_scan) lists every
+                # complete frame ahead in one pass; whatever it cannot finish is left to the byte-wise parser below
+                stop = self._take_scanned(pieces, close_run, lambda k, e: self._append(k, e))
+                frames += self._scanned_frames
+                run_key, run = self._run_key, self._run
+                if stop == "flush":
+                    close_run()
+                    pieces.append(self.flush().pcm)
+                    break
+                if stop == "crit":
+                    close_run()
+                    pieces.append(self.flush().pcm)
+                    return DecodeResult(pieces, self._crit_srate, frames, True)
+                if stop == "end":
+                    break
+                # "partial": fall through, the byte-wise parser takes the unfinished header / payload
             if not self._lock_on_signature():
                 break
             state = self._read_header()
@@ -245,8 +286,63 @@ class Decoder:
         close_run()
         return DecodeResult(pieces, self.asfh.srate, frames, False)
 
+    # ------------------------------------------------------------------ table-driven parsing (native scanner)
+    @property
+    def _scan(self):
+        """frad_asfh_scan of the loaded C-ABI library, or None when the bridge is not the HIP one (CPU-only tests keep the
+        byte-wise parser, which is the reference's algorithm)."""
+        lib = getattr(self.bridge, "scan_lib", None)
+        return lib.asfh_scan if lib is not None else None
+
+    def _append(self, key, entry):
+        if key != self._run_key or (key[0] != 1 and self._run and entry[2] != self._run[0][2]):
+            if self._run:
+                self._pieces.extend(self._decode_run(self._run_key, self._run))
+            self._run_key, self._run = key, []
+        self._run.append(entry)
+
+    def _take_scanned(self, pieces, close_run, append) -> str:
+        """Consume the frames the scanner found from self._pos on.  Returns why it stopped: 'end' (nothing more in the
+        buffer), 'partial' (an unfinished header or payload follows at self._pos), 'flush' (a force-flush header was
+        consumed) or 'crit' (channels / rate changed, decoder.py:93-98)."""
+        self._pieces, self._scanned_frames = pieces, 0
+        close_run()
+        self._run_key, self._run = None, []
+        table, next_pos, why = self._scan(self._data, self._pos)
+        a = self.asfh
+        rows = table.tolist()
+        for (h_off, p_off, p_len, profile, ecc, le, depth, ch, srate, fsize, ratio, dsize, csize, fflush, crc) in rows:
+            a.profile, a.ecc, a.endian, a.bit_depth_index = profile, bool(ecc), bool(le), depth
+            a.channels, a.srate, a.fsize, a.frmbytes = ch, srate, fsize, p_len
+            if fflush:
+                self._pos = p_off
+                return "flush"
+            a.overlap_ratio, a.ecc_dsize, a.ecc_codesize = ratio, dsize, csize
+            if not a.criteq(self.info):
+                previous = (self.info.srate, self.info.channels)
+                self.info = a
+                if any(previous):
+                    self._pos, self._crit_srate = p_off, previous[0]
+                    return "crit"
+            if profile not in (0, 1, 4):
+                raise NotImplementedError(f"profile {profile} is not built (upstream: in development)")
+            frad = None
+            if profile == 1 or ecc:
+                frad = self._data[p_off:p_off + p_len]
+                if ecc:
+                    frad = _strip_ecc(frad, dsize, csize)
+            key = (profile, fsize, ch, depth, bool(le), srate, ratio)
+            append(key, (frad, p_off, p_len if frad is None else len(frad)))
+            self._scanned_frames += 1
+            self._pos = p_off + p_len
+            self.broken_frame = False
+        if why == 0:                                            # FRAD_SCAN_END: keep a possibly split signature
+            self._pos = max(self._pos, next_pos)
+            return "end"
+        return "partial"
+
     def flush(self) -> DecodeResult:
         ret = self.overlap_fragment
         self.overlap_fragment = np.array([])
         self.asfh.clear()
-        return DecodeResult([ret], self.asfh.srate, 0, False)
+        return self._narrow(DecodeResult([ret], self.asfh.srate, 0, False))

@@ -167,6 +167,38 @@ int frad_p1_golomb_decode(const void* bodies, const int64_t* offsets, int64_t n_
  * stream can be assembled without a host pass over the payload.                                   */
 int frad_crc32_frames(const void* data, int64_t stride, int64_t n_frames, int64_t nbytes, uint32_t* crc_out, void* stream);
 
+/* ---- decoder output conversion (R1 epilogue) and native frame-header scan (row 8f #1) ------------------------------
+ * frad_from_f64 == backend.pcmformat.from_f64 followed by .astype(fmt) as the reference's caller applies it to every
+ * decoded block (backend/pcmformat.py:49-62, src/decoder.py:23): float64 [n_values] -> `out_dtype` (FRAD_PCM_*), floats
+ * rounded to nearest even, integers scaled and truncated; samples outside the integer range come out as numpy's astype
+ * leaves them on x86-64 (cvttsd2si: low bits of the 32/64-bit conversion, 0x80..0 on overflow and for NaN).
+ * flags: FRAD_RAW_BE_INTS reproduces the reference's quirk that big-endian integer formats are not recognised by
+ * from_f64 (pcmformat.py:52-60 compares against native dtypes), so the unscaled float64 samples are truncated;
+ * FRAD_LITTLE_ENDIAN is the payload endianness as in frad_p{0,4}_digital.
+ * frad_p{0,4,1}_digital_pcm == frad_p{0,4,1}_digital with that conversion applied on the way out (profile 4: fused into
+ * the unpack; profile 0 / 1: a second pass over stream-ordered scratch), pcm_out [n_frames, N, C] of out_dtype.    */
+int frad_from_f64(const double* pcm, int64_t n_values, int32_t out_dtype, uint32_t flags, void* out, void* stream);
+int frad_p0_digital_pcm(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C, int32_t bits,
+                        uint32_t flags, int32_t out_dtype, void* pcm_out, void* stream);
+int frad_p4_digital_pcm(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C, int32_t bits,
+                        uint32_t flags, int32_t out_dtype, void* pcm_out, void* stream);
+int frad_p1_digital_pcm(const int32_t* q, const int32_t* tq, int64_t n_frames, int32_t N, int32_t C, int32_t bits,
+                        int32_t srate, int32_t out_dtype, uint32_t flags, void* pcm_out, void* stream);
+
+/* frad_asfh_scan: HOST code (no device involved).  One pass over a FrAD byte stream from `start`: resynchronises on
+ * FRM_SIGN and parses every header as ASFH.read does (tools/asfh.py:98-134; the search as decoder.py:82-90), filling
+ * frames[0 .. return value).  Stops at the first header or payload that is not completely inside the buffer, at
+ * max_frames, or at the end; *next_pos = where the next call (with more data appended) must resume, *stop_reason says
+ * why.  Force-flush headers are table rows with force_flush = 1 and no payload.  Returns the row count or FRAD_E_INVALID. */
+typedef struct frad_frame_info {
+    int64_t header_off, payload_off, payload_bytes;
+    int32_t profile, ecc, little_endian, depth_idx, channels, srate, fsize, overlap_ratio, ecc_dsize, ecc_codesize, force_flush;
+    uint32_t crc;                                 /* crc32 of the payload (lossless) / crc16 (compact with ECC) as stored */
+} frad_frame_info;
+enum { FRAD_SCAN_END = 0, FRAD_SCAN_PARTIAL_HEADER = 1, FRAD_SCAN_PARTIAL_PAYLOAD = 2, FRAD_SCAN_TABLE_FULL = 3 };
+int64_t frad_asfh_scan(const void* stream_bytes, int64_t nbytes, int64_t start, frad_frame_info* frames, int64_t max_frames,
+                       int64_t* next_pos, int32_t* stop_reason);
+
 /* ---- measurement aid (not on the codec path) ----------------------------------------------------
  * dst[0, nbytes) = src[0, nbytes): device-to-device, 16 bytes per lane, the access shape of the
  * transform kernels.  bench.py times it as the "achievable HBM bandwidth" yardstick next to the

@@ -17,11 +17,17 @@ def _bridge(kind):
     if kind == "host":
         from helpers import OracleBridge
         return OracleBridge()
+    if kind == "host-scan":                                   # oracle arithmetic + the native header scanner (host C++)
+        from helpers import OracleBridge, build_emulator
+        from frad_python_amd._lib import FradLib
+        b = OracleBridge()
+        b.scan_lib = FradLib(build_emulator())
+        return b
     from frad_python_amd.bridge import HipBridge
     return HipBridge()
 
 
-@pytest.fixture(params=[pytest.param("host"), pytest.param("gpu", marks=pytest.mark.gpu)])
+@pytest.fixture(params=[pytest.param("host"), pytest.param("host-scan"), pytest.param("gpu", marks=pytest.mark.gpu)])
 def kind(request):
     return request.param
 
@@ -85,7 +91,7 @@ def test_streams_encode_byte_for_byte_and_decode(kind):
             out, samples = _encode(kind, pcm, chunk, p)
             assert samples == c["samples"], c["name"]
             assert len(out) == c["nbytes"] or (kind == "gpu" and lossy), c["name"]
-            if kind == "host" or p["profile"] == 4:
+            if kind.startswith("host") or p["profile"] == 4:
                 assert hashlib.sha256(out).hexdigest() == c["sha256"], (c["name"], chunk)
             elif not lossy:
                 # profile 0 on the GPU: payload words identical up to rare double-rounding ties -> compare values
@@ -124,7 +130,7 @@ def test_streams_encode_byte_for_byte_and_decode(kind):
         got, frames = _decode(kind, ref_stream, 777, p["channels"])
         want = fo.decode_stream(ref_stream)
         assert frames == c["frames"] and list(got.shape) == c["decoded_shape"], c["name"]
-        if kind == "host" or p["profile"] == 4:
+        if kind.startswith("host") or p["profile"] == 4:
             assert hashlib.sha256(np.ascontiguousarray(got).astype("<f8").tobytes()).hexdigest() == c["decoded_sha256"], c["name"]
         else:
             assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, np.max(np.abs(want))), c["name"]
@@ -209,3 +215,28 @@ def test_encoder_is_transactional_on_device_errors():
     out = enc.process(pcm).buf + enc.flush().buf
     want = fo.encode_stream(pcm, profile=0, srate=48000, channels=2, bits=32, frame_size=1024, pcm_format="s16le")
     assert out == want
+
+
+@pytest.mark.parametrize("fmt", ["s16le", "f32le", "s32be"])
+def test_decoder_output_format(kind, fmt):
+    """Decoder(out_format=...) == from_f64(Decoder().pcm, fmt).astype(fmt) as the reference's caller computes it after
+    every process() (src/decoder.py:23), for lossless and lossy streams incl. the tail frame and the flush."""
+    from frad_python_amd.backend.pcmformat import ff_format_to_numpy_type
+    dt = ff_format_to_numpy_type(fmt)
+    pcm = synth.to_pcm(synth.harmonic_mix(7000, 2, 48000, seed=5), "s16le").tobytes()
+    for p in (dict(profile=4, srate=48000, channels=2, bits=16, frame_size=1024, pcm_format="s16le"),
+              dict(profile=0, srate=48000, channels=2, bits=32, frame_size=2048, pcm_format="s16le"),
+              dict(profile=1, srate=48000, channels=2, bits=16, frame_size=2048, pcm_format="s16le", overlap_ratio=16)):
+        stream = fo.encode_stream(pcm, **p)
+        plain, frames = _decode(kind, stream, 5000, 2)
+        dec = Decoder(bridge=_bridge(kind), out_format=fmt)
+        got = []
+        for i in range(0, len(stream), 5000):
+            got.append(dec.process(stream[i:i + 5000]).pcm.reshape(-1, 2))
+        got.append(dec.flush().pcm.reshape(-1, 2))
+        assert all(g.dtype == dt for g in got if g.size)
+        got = np.concatenate([g for g in got if g.size]).astype(dt)
+        with np.errstate(all="ignore"):
+            want = fo.from_f64(plain, dt).astype(dt)
+        assert got.dtype == dt and got.shape == want.shape, (p["profile"], got.dtype, got.shape, want.shape)
+        assert got.tobytes() == want.tobytes(), p["profile"]
