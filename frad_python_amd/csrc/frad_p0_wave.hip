@@ -162,4 +162,14 @@ int launch_p0_inv_wave(hipStream_t s, const unsigned char* pay, double* out, con
     return 1;
 }
 
+
+// shared with the profile-1 wave kernels (frad_p1_wave.hip)
+const void* wave_blob_get(unit_root_fn unit) { return wave_blob(unit); }
+int wave_grid(long long units) {
+    const long long nb = (units + kWaveWaves - 1) / kWaveWaves, cap = wave_cu_count();
+    return (int)(nb < cap ? nb : cap);
+}
+bool wave_off() { return wave_disabled(); }
+int wave_stagger_steps() { return wave_stagger(); }
+
 }  // namespace frad

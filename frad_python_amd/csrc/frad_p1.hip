@@ -1,5 +1,6 @@
 // profile 1 (psychoacoustic quantiser) entry points -- kernels K7 / K8 (frad_p1.hpp).
 #include "frad_p1.hpp"
+#include "frad_wave.hpp"
 #include "frad_launch.hpp"
 #include "../../include/frad_hip.h"
 
@@ -140,6 +141,29 @@ bool p1_fast_fits(FastCfg& c, int N, int C) {
     return (size_t)c.fpb * C * M * 16 + p1_scratch_bytes(c.fpb * C, N) <= 160 * 1024;
 }
 
+P1Wave wave_tables(const P1Tables& tb, int N) {
+    P1Wave pw{};
+    for (int i = 0; i < 28; ++i) pw.edge[i] = tb.edge[i] < N ? tb.edge[i] : N;
+    for (int i = 0; i < 27; ++i) pw.floor_[i] = tb.floor_[i];
+    pw.scale = tb.scale; pw.loss = tb.loss; pw.nb_used = tb.nb_used; pw.band_of = tb.band_of; pw.tq_in = nullptr; pw.tq_out = nullptr;
+    return pw;
+}
+// the root-of-unity generator the wave table blob is built with (the same values as frad_hip.hip's tables)
+void p1_unit_neg(long long p, long long q, long double& re, long double& im) {
+    const long double PI = 3.14159265358979323846264338327950288419716939937510L;
+    long long r = p % (2 * q); if (r < 0) r += 2 * q;
+    const long long h = q / 2;
+    const int quad = (int)(r / h);
+    const long long rem = r % h;
+    long double c, s;
+    if (4 * rem <= q) { c = cosl(PI * (long double)rem / (long double)q); s = sinl(PI * (long double)rem / (long double)q); }
+    else { c = sinl(PI * (long double)(h - rem) / (long double)q); s = cosl(PI * (long double)(h - rem) / (long double)q); }
+    if (rem == 0) { c = 1.0L; s = 0.0L; }
+    long double C, S;
+    switch (quad) { case 0: C = c; S = s; break; case 1: C = -s; S = c; break; case 2: C = -c; S = -s; break; default: C = s; S = -c; }
+    re = C; im = -S;
+}
+
 Geom p1_geom(long long n_frames, int N, int C, long long stride, int n_valid, int dtype, uint32_t flags) {
     Geom g{};
     g.n_frames = n_frames; g.frame_stride = stride; g.payload_stride = 0; g.N = N; g.C = C; g.bits = 32; g.le = 0;
@@ -180,6 +204,11 @@ int frad_p1_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
     const int ai = ((reinterpret_cast<uintptr_t>(pcm) & 15u) == 0 && (((frame_stride * C) << lg) % 16 == 0) &&
                     ((((long long)N * C) << lg) % 16 == 0)) ? 1 : 0;
     const unsigned char* in = static_cast<const unsigned char*>(pcm);
+    if (!tb.f32) {
+        P1Wave pw = wave_tables(tb, N);
+        pw.tq_out = tq;
+        if (launch_p1_fwd_wave(lg, s, in, q, g, pw, ai, p1_unit_neg)) { P1CHK(hipGetLastError()); return FRAD_OK; }
+    }
     FastCfg c = fast_cfg(N, C, false);
     if (p1_fast_fits(c, N, C)) {
         const int M = 1 << c.log2m;
@@ -242,6 +271,11 @@ int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32
     if (rc != FRAD_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Geom g = p1_geom(n_frames, N, C, N, N, FRAD_PCM_F64LE, 0);
+    {
+        P1Wave pw = wave_tables(tb, N);
+        pw.tq_in = tq;
+        if (launch_p1_inv_wave(s, q, pcm_out, g, pw, p1_unit_neg)) { P1CHK(hipGetLastError()); return FRAD_OK; }
+    }
     FastCfg c = fast_cfg(N, C, false);
     if (p1_fast_fits(c, N, C)) {
         const int M = 1 << c.log2m;

@@ -9,6 +9,7 @@
 // Float64 throughout, like the reference on integer / f64 PCM.  Exp-Golomb + deflate stay on the host.
 #pragma once
 #include "frad_kernels.hpp"
+#include "frad_wave.hpp"
 #include <math.h>
 
 namespace frad {
@@ -26,18 +27,6 @@ struct P1Tables {
     int f32;                     // float32 / float16 PCM: the reference does not widen it (pcmformat.py:35), so its DCT
                                  // and band energies are float32 and only the divide + quantiser are float64
 };
-
-// Band energy -> masking threshold of one band (p1tools.py:18-33).  `f32`: numpy's types on float32 coefficients --
-// mean, sqrt and the 0.8 power stay float32, and the product with the loss level does too when the signal term wins.
-__device__ __forceinline__ double p1_band_threshold(double energy, int bins, double floor_, double loss, int f32) {
-    if (!f32) {
-        const double sfq = pow(sqrt(energy / (double)bins), 0.8);
-        return (floor_ > sfq ? floor_ : sfq) * loss;
-    }
-    const float mean = (float)(energy / (double)bins);
-    const float sfq = powf(sqrtf(mean), 0.8f);
-    return floor_ > (double)sfq ? floor_ * loss : (double)(sfq * (float)loss);
-}
 
 // frad_global.hip: profile 1 through HBM workspaces (frames wider than a CU's LDS at a non-power-of-two size)
 int global_p1_analogue(const unsigned char* pcm, int32_t* q, int32_t* tq, const Geom& g, const P1Tables& tb, hipStream_t s);

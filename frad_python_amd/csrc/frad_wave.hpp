@@ -195,6 +195,61 @@ __device__ __forceinline__ double wave_elem(uint32_t word, int shift) {
     }
 }
 
+// ---- profile 1 on the same wave-per-frame structure (MODE 1 of the kernel bodies below) ------------------------------
+// K8 = the decode body with the payload words replaced by the quantised integers (q has the layout of a 32-bit payload:
+// bin-major, channel-minor, 4 bytes) and `value` = dequantise x threshold ramp (profile1.py:65-77); K7 = the encode body
+// with the storage cast replaced by band energies -> thresholds -> per-bin divide + power-law quantiser (profile1.py:
+// 15-40, p1tools.py:15-44).  Per-launch constants arrive by value and are copied to LDS once per block.
+struct P1Wave {
+    int edge[28];                // band edges in bins, clipped to N (p1tools.py:15-16)
+    double floor_[27];           // min(ATH, 1.0) per band
+    double scale, loss;          // 2^(bits-1); max(|loss_level|, 0.125)
+    int nb_used;                 // bands before the first empty one
+    const unsigned char* band_of;// device table [N]: band of bin k (0..25), 255 = beyond the last band start
+    const int32_t* tq_in;        // K8: [n_frames, 27, C]
+    int32_t* tq_out;             // K7: [n_frames, 27, C]
+};
+struct P1None {};
+constexpr int kP1BlockBytes = 2048 + 32 * 4 + 32 * 8;        // band_of[2048] | edge[32] | floor[32], after the work counter
+constexpr int kWaveLdsBytesP1 = kWaveLdsBytes + 16 + kP1BlockBytes;
+struct P1Lds2 { const unsigned char* band; const int* edge; const double* floor_; };
+__device__ __forceinline__ P1Lds2 p1w_lds(unsigned char* smem) {
+    unsigned char* b = smem + kWaveLdsBytes + 16;
+    return {b, reinterpret_cast<const int*>(b + 2048), reinterpret_cast<const double*>(b + 2048 + 128)};
+}
+__device__ __forceinline__ void p1w_tables_to_lds(unsigned char* smem, const P1Wave& pw) {
+    unsigned char* b = smem + kWaveLdsBytes + 16;
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) reinterpret_cast<uint32_t*>(b)[i] = reinterpret_cast<const uint32_t*>(pw.band_of)[i];
+    if (threadIdx.x < 28) reinterpret_cast<int*>(b + 2048)[threadIdx.x] = pw.edge[threadIdx.x];
+    if (threadIdx.x < 27) reinterpret_cast<double*>(b + 2048 + 128)[threadIdx.x] = pw.floor_[threadIdx.x];
+}
+// per-wave scratch at the start of the wave's buffer: thr[2][32] | stp[2][32] | acc[2][32] doubles (index h * 32 + band)
+__device__ __forceinline__ double p1w_spread(const P1Lds2& t, const double* thr, const double* stp, int h, int k) {
+    const int j = t.band[k];
+    if (j >= 26) return 0.0;
+    const int a = t.edge[j];
+    const double i = (double)(k - a), st = stp[h * 32 + j], t0 = thr[h * 32 + j];
+    double y = i * st;
+    if (st == 0.0) y = (i / (double)(t.edge[j + 1] - a)) * (thr[h * 32 + j + 1] - t0);      // numpy's denormal-safe branch
+    return y + t0;
+}
+__device__ __forceinline__ double p1w_quant(double x) {        // sign(x) |x|^0.75 (p1tools.py:43)
+    const double a = fabs(x), r = sqrt(a);
+    return copysign(r * sqrt(r), x) * (a != 0.0);
+}
+__device__ __forceinline__ double p1w_dequant(double x) { const double a = fabs(x); return copysign(a * cbrt(a), x) * (a != 0.0); }
+// Band energy -> masking threshold of one band (p1tools.py:18-33).  `f32`: numpy's types on float32 coefficients --
+// mean, sqrt and the 0.8 power stay float32, and the product with the loss level does too when the signal term wins.
+__device__ __forceinline__ double p1_band_threshold(double energy, int bins, double floor_, double loss, int f32) {
+    if (!f32) {
+        const double sfq = pow(sqrt(energy / (double)bins), 0.8);
+        return (floor_ > sfq ? floor_ : sfq) * loss;
+    }
+    const float mean = (float)(energy / (double)bins);
+    const float sfq = powf(sqrtf(mean), 0.8f);
+    return floor_ > (double)sfq ? floor_ * loss : (double)(sfq * (float)loss);
+}
+
 // =============================================================================================
 // encode: PCM -> payload.  grid = min(ceil(units / 7), CUs), block = 448 (7 independent waves).
 // unit = one frame (CC == 2) or a pair of frames 2u, 2u+1 (CC == 1).
@@ -215,6 +270,186 @@ __device__ __forceinline__ double wave_elem(uint32_t word, int shift) {
 // with two waves per SIMD an LDS round trip (hundreds of cycles behind the other waves' bursts) is otherwise exposed.
 // =============================================================================================
 #define FRAD_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// sums over the two 32-lane halves of a wave (all lanes get both)
+__device__ __forceinline__ void half_wave_sum_f64(double v, double& lo, double& hi) {
+#ifdef FRAD_HOST_EMULATION
+    for (int off = 1; off < 32; off <<= 1) v = v + u2d(__shfl_xor(d2u(v), off, 64));
+    const double other = u2d(__shfl_xor(d2u(v), 32, 64));
+    const bool up = (threadIdx.x & 32) != 0;
+    lo = up ? other : v; hi = up ? v : other;
+#else
+    v = v + u2d(dpp_move_u64<0xB1>(d2u(v)));
+    v = v + u2d(dpp_move_u64<0x4E>(d2u(v)));
+    v = v + u2d(dpp_move_u64<0x141>(d2u(v)));
+    v = v + u2d(dpp_move_u64<0x140>(d2u(v)));
+    lo = u2d(read_lane_u64(d2u(v), 0)) + u2d(read_lane_u64(d2u(v), 16));
+    hi = u2d(read_lane_u64(d2u(v), 32)) + u2d(read_lane_u64(d2u(v), 48));
+#endif
+}
+__device__ __forceinline__ int wave_uniform_int(int v) {
+#ifdef FRAD_HOST_EMULATION
+    return (int)__shfl((unsigned long long)(unsigned)v, 0, 64);
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+// the 32 consecutive bins a half-wave holds for job slot s, class cls (0: k, 1: M - k, 2: M + k, 3: N - k): first, last
+__host__ __device__ constexpr int wave_seg_lo(int s, int cls) {
+    const int t = s < 8 ? s : 15 - s, a = s < 8 ? 64 * t : 64 * t + 32;            // k in [a, a + 31]
+    return cls == 0 ? a : cls == 1 ? (s == 0 ? 993 : 1024 - a - 31) : cls == 2 ? 1024 + a : (s == 0 ? 2017 : 2048 - a - 31);
+}
+__host__ __device__ constexpr int wave_seg_hi(int s, int cls) {
+    const int t = s < 8 ? s : 15 - s, a = s < 8 ? 64 * t : 64 * t + 32;
+    return cls == 0 ? a + 31 : cls == 1 ? (s == 0 ? 1023 : 1024 - a) : cls == 2 ? 1024 + a + 31 : (s == 0 ? 2047 : 2048 - a);
+}
+
+// K7 tail: Z (E, O as pass 2 leaves them) -> DCT pair step -> band energies -> thresholds -> quantised integers.
+// The pair step is cheap next to a second set of 64 registers per lane, so it runs twice: once for the energies (segmented
+// half-wave sums: a job's 32 bins per channel are consecutive, the bands they touch are wave-uniform), once for the quantiser.
+template <int CC, typename T>
+__device__ __forceinline__ void wave_p1_quantise(const cx<T> (&E)[16], const cx<T> (&O)[16], const cx<T>* ltab, unsigned char* smem,
+                                                 unsigned char* wbuf, int32_t* __restrict__ q, const P1Wave& pw, const Geom& g,
+                                                 long long u, int lane) {
+    constexpr int M = 1024, N = 2048;
+    const int h = lane >> 5, l = lane & 31;
+    const bool lane0 = (l == 0);
+    const long long f = CC == 2 ? u : 2 * u + h;
+    const bool live = f < g.n_frames;
+    const int c = CC == 2 ? h : 0;
+    const P1Lds2 p1t = p1w_lds(smem);
+    double* thr = reinterpret_cast<double*>(wbuf); double* stp = thr + 64;
+    auto sel = [&](cx<T> a, cx<T> b) { return cx<T>{lane0 ? a.x : b.x, lane0 ? a.y : b.y}; };
+    // X of job slot s: x[0] = X[k], x[1] = X[M - k], x[2] = X[M + k], x[3] = X[N - k] (the profile-0 arithmetic); lane 0 of
+    // slot 0 (k = 0) has X[0] and, in x[2], X[M]; its x[1], x[3] name no bin
+    auto job = [&](int s, cx<T> wk, cx<T> gk, T (&x)[4]) {
+        const cx<T> zk = s < 8 ? E[s] : O[15 - s];
+        const cx<T> zm = s < 8 ? sel(E[(16 - s) & 15], O[15 - s]) : sel(O[s], E[s]);
+        const cx<T> zp = conj(zm);
+        const cx<T> p = cmul(zk + zp, wk), qq = cmul(zk - zp, gk);
+        const cx<T> S = p + qq, D = p - qq;
+        const T xm = (D.x - D.y) * K<T>::s2, xp = (D.x + D.y) * K<T>::s2;
+        x[0] = S.x; x[1] = xm; x[2] = (s == 0 && lane0) ? xm : xp; x[3] = -S.y;
+    };
+    cx<T> ptab[2][2];
+    auto ptab_load = [&](int s) {
+        ptab[s & 1][0] = ltab[WaveLayout::PW + s * 32 + l];
+        ptab[s & 1][1] = ltab[WaveLayout::PG + s * 32 + l];
+    };
+    // The 32 bins a half-wave holds per (slot, class) are consecutive, so the bands they touch are the same for every
+    // lane and both channels: band range and edges are wave-uniform (scalar registers), membership is two compares, and
+    // nothing is gathered per lane.
+    auto seg_bands = [&](int s, int cls, int& blo, int& bhi) {
+        blo = wave_uniform_int((int)p1t.band[wave_seg_lo(s, cls)]);
+        bhi = wave_uniform_int((int)p1t.band[wave_seg_hi(s, cls)]);
+        if (bhi > 25) bhi = 25;                               // 255: beyond the last band start -- no band there
+    };
+    // ---- pass A: band energies sum((X * scale)^2) (p1tools.py:21-29); lane b of each half accumulates band b ----------
+    double accreg = 0.0;
+    ptab_load(0);
+    FRAD_FENCE();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        if (s + 1 < 16) ptab_load(s + 1);
+        FRAD_FENCE();
+        T x[4];
+        job(s, ptab[s & 1][0], ptab[s & 1][1], x);
+        const int kq = wave_job_k(l, s);
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) {
+            const bool valid = !(s == 0 && lane0 && (cls & 1));
+            const int kb = cls == 0 ? kq : cls == 1 ? M - kq : cls == 2 ? M + kq : N - kq;
+            const T v = x[cls] * pw.scale;
+            const T v2 = valid ? v * v : 0.0;
+            int blo, bhi;
+            seg_bands(s, cls, blo, bhi);
+            for (int b = blo; b <= bhi; ++b) {
+                const int ea = wave_uniform_int(p1t.edge[b]), eb = wave_uniform_int(p1t.edge[b + 1]);
+                double s0, s1;
+                half_wave_sum_f64((kb >= ea && kb < eb) ? v2 : 0.0, s0, s1);
+                accreg += (l == b) ? (h ? s1 : s0) : 0.0;
+            }
+        }
+        FRAD_FENCE();
+    }
+    T xs[2] = {0.0, 0.0};                                         // lane 0: the self-paired bin k = 512 -> X[512], X[1536]
+    {
+        const cx<T> zk = E[8], zp = conj(E[8]);
+        const cx<T> p = cmul(zk + zp, ltab[WaveLayout::TW1 + 0]), qq = cmul(zk - zp, ltab[WaveLayout::TW1 + 1]);
+        const cx<T> S = p + qq;
+        xs[0] = S.x; xs[1] = -S.y;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int jb = wave_uniform_int((int)p1t.band[512 + 1024 * i]);
+            const T v = xs[i] * pw.scale;
+            double s0, s1;
+            half_wave_sum_f64(lane0 ? v * v : 0.0, s0, s1);
+            accreg += (jb < 26 && l == jb) ? (h ? s1 : s0) : 0.0;
+        }
+    }
+    // ---- thresholds (p1tools.py:18-33), their quantised form (profile1.py:38-40), ramp steps (p1tools.py:35-41) ----
+    if (l < 27) {
+        const int b = l, bins = p1t.edge[b + 1] - p1t.edge[b];
+        double t = 0.0;
+        if (b < pw.nb_used) t = p1_band_threshold(accreg, bins, p1t.floor_[b], pw.loss, 0);
+        thr[h * 32 + b] = t;
+        if (live) {
+            const double v = log(t > 1.0 ? t : 1.0) / log(2.718281828459045 / 2);
+            pw.tq_out[(f * 27 + b) * CC + c] = (int32_t)rint(copysign(pow(fabs(v), 1.0 / 0.75), v));
+        }
+    }
+    team_sync<64>();
+    if (l < 27) {
+        double st = 0.0;
+        if (l < 26) { const int num = p1t.edge[l + 1] - p1t.edge[l]; if (num > 0) st = (thr[h * 32 + l + 1] - thr[h * 32 + l]) / (double)num; }
+        stp[h * 32 + l] = st;
+    }
+    team_sync<64>();
+    // ---- pass B: per-bin divide + power-law quantiser (profile1.py:27-36), 256 contiguous bytes per store ----------
+    int32_t* qf = q + (live ? f : 0) * (long long)N * CC + c;
+    auto quant_div = [&](T x, double div) -> int32_t {
+        const double m = (div == 0.0) ? 0.0 * x : x / div;      // x / inf keeps the sign of x
+        return (int32_t)rint(p1w_quant(m * pw.scale));
+    };
+    // threshold ramp at bin kb of band b (np.linspace without its end point; numpy's branch for a vanishing step)
+    auto ramp = [&](int b, int ea, int eb, int kb) -> double {
+        const double t0 = thr[h * 32 + b], st = stp[h * 32 + b], i = (double)(kb - ea);
+        double y = i * st;
+        if (st == 0.0) y = (i / (double)(eb - ea)) * (thr[h * 32 + b + 1] - t0);
+        return y + t0;
+    };
+    ptab_load(0);
+    FRAD_FENCE();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        if (s + 1 < 16) ptab_load(s + 1);
+        FRAD_FENCE();
+        T x[4];
+        job(s, ptab[s & 1][0], ptab[s & 1][1], x);
+        const int kq = wave_job_k(l, s);
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) {
+            const bool valid = !(s == 0 && lane0 && (cls & 1));
+            const int kb = cls == 0 ? kq : cls == 1 ? M - kq : cls == 2 ? M + kq : N - kq;
+            int blo, bhi;
+            seg_bands(s, cls, blo, bhi);
+            double div = 0.0;                                    // bins beyond the last band start divide by 0 -> 0
+            for (int b = blo; b <= bhi; ++b) {
+                const int ea = wave_uniform_int(p1t.edge[b]), eb = wave_uniform_int(p1t.edge[b + 1]);
+                const double d = ramp(b, ea, eb, kb);
+                div = (kb >= ea && kb < eb) ? d : div;
+            }
+            const int32_t qv = quant_div(x[cls], div);
+            if (valid && live) *FRAD_GPTR(int32_t, qf + (long long)kb * CC) = qv;
+        }
+        FRAD_FENCE();
+    }
+    auto quant = [&](T x, int kbin) -> int32_t { return quant_div(x, p1w_spread(p1t, thr, stp, h, kbin)); };
+    if (lane0 && live) {
+        *FRAD_GPTR(int32_t, qf + 512LL * CC) = quant(xs[0], 512);
+        *FRAD_GPTR(int32_t, qf + 1536LL * CC) = quant(xs[1], 1536);
+    }
+}
 #ifndef FRAD_WAVE_DMA_AUX
 #define FRAD_WAVE_DMA_AUX 2                     // nt: the PCM is read once
 #endif
@@ -228,10 +463,10 @@ __device__ __forceinline__ double wave_elem(uint32_t word, int shift) {
 #define FRAD_WAVE_PRB 4
 #endif
 
-template <int LG, int CC, int BITS>
-__global__ void FRAD_WAVE_BOUNDS
-k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload, double* absmax,
-              const cx<double>* __restrict__ blob, Geom g) {
+template <int LG, int CC, int BITS, int MODE, typename P1>
+__device__ __forceinline__ void
+wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload, double* absmax,
+              const cx<double>* __restrict__ blob, const Geom& g, const P1& pw) {
     using T = double;
     constexpr int M = 1024, N = 2048, ISZ = 1 << LG, NB = BITS / 8;
     static_assert(BITS == 16 || BITS == 32 || BITS == 64, "whole-byte power-of-two storage");
@@ -258,6 +493,7 @@ k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         }
     }
     const cx<T>* ltab = reinterpret_cast<const cx<T>*>(smem);
+    if constexpr (MODE == 1) p1w_tables_to_lds(smem, pw);
 #ifdef FRAD_HOST_EMULATION
     const int wv = threadIdx.x >> 6;
 #else
@@ -328,7 +564,7 @@ k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
 #ifndef FRAD_HOST_EMULATION
             // this unit's DMA was issued before the previous unit's 4 NB row stores: vector-memory operations retire
             // in order, so at most that many may still be in flight
-            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(4 * NB) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(MODE == 1 ? 60 : 4 * NB) : "memory");   // (profile 1: 67 stores follow the DMA)
 #endif
             FRAD_STAMP(0);
             team_sync<64>();
@@ -513,6 +749,9 @@ k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         tw32_apply<false>(O);
         dft<16, false>(O);                                     // O[u] = Z[b + 32 (2 u + 1)]
         FRAD_FENCE();
+        if constexpr (MODE == 1) {
+            wave_p1_quantise<CC>(E, O, ltab, smem, wbuf, reinterpret_cast<int32_t*>(payload), pw, g, u, lane);
+        } else {
         ptab_load(NG - 1, 0);
         FRAD_FENCE();
         FRAD_STAMP(4);
@@ -644,6 +883,7 @@ k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
                 }
             }
         }
+        }                                                      // MODE 0
         team_sync<64>();
         FRAD_STAMP(6);
 #if defined(FRAD_WAVE_STAMPS) && !defined(FRAD_HOST_EMULATION)
@@ -652,6 +892,19 @@ k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         u = next;
     }
     FRAD_STAMP_FLUSH;
+}
+
+template <int LG, int CC, int BITS>
+__global__ void FRAD_WAVE_BOUNDS
+k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload, double* absmax,
+              const cx<double>* __restrict__ blob, Geom g) {
+    wave_fwd_body<LG, CC, BITS, 0>(pcm, payload, absmax, blob, g, P1None{});
+}
+// K7: PCM -> q int32 [n_frames, 2048, C] + pw.tq_out [n_frames, 27, C]  (full frames, integer or f64 PCM)
+template <int LG, int CC>
+__global__ void FRAD_WAVE_BOUNDS
+k_p1_fwd_wave(const unsigned char* __restrict__ pcm, int32_t* __restrict__ q, const cx<double>* __restrict__ blob, Geom g, P1Wave pw) {
+    wave_fwd_body<LG, CC, 32, 1>(pcm, reinterpret_cast<unsigned char*>(q), nullptr, blob, g, pw);
 }
 
 
@@ -685,11 +938,12 @@ template <typename T> __device__ __forceinline__ cx<T> cmulc(cx<T> a, cx<T> w) {
     return {fma(a.x, w.x, a.y * w.y), fma(a.y, w.x, -(a.x * w.y))};
 }
 
-template <int CC, int BITS>
-__global__ void FRAD_WAVE_BOUNDS
-k_p0_inv_wave(const unsigned char* __restrict__ payload, double* __restrict__ out, const cx<double>* __restrict__ blob, Geom g) {
+template <int CC, int BITS, int MODE, typename P1>
+__device__ __forceinline__ void
+wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ out, const cx<double>* __restrict__ blob, const Geom& g, const P1& pw) {
     using T = double;
     constexpr int M = 1024, N = 2048, NB = BITS / 8;
+    static_assert(MODE == 0 || BITS == 32, "profile 1: the integers have the layout of a 32-bit payload");
     static_assert(BITS == 16 || BITS == 32 || BITS == 64, "whole-byte power-of-two storage");
     static_assert(CC == 1 || CC == 2, "channels");
     constexpr int FPW = 2 / CC;
@@ -701,6 +955,7 @@ k_p0_inv_wave(const unsigned char* __restrict__ payload, double* __restrict__ ou
         for (int i = threadIdx.x; i < WaveLayout::SLOTS; i += blockDim.x) l[i] = blob[i];
     }
     const cx<T>* ltab = reinterpret_cast<const cx<T>*>(smem);
+    if constexpr (MODE == 1) p1w_tables_to_lds(smem, pw);
 #ifdef FRAD_HOST_EMULATION
     const int wv = threadIdx.x >> 6;
 #else
@@ -763,7 +1018,17 @@ k_p0_inv_wave(const unsigned char* __restrict__ payload, double* __restrict__ ou
             w[s][3] = fetch(pC[j] + o);
         }
     };
-    auto value = [&](code_t c) -> T {                          // stored code -> float64, NaN / Inf -> 0 (profile0.py:62-66)
+    [[maybe_unused]] const P1Lds2 p1t = p1w_lds(smem);
+    [[maybe_unused]] double* const thr = reinterpret_cast<double*>(wbuf);      // MODE 1: this wave's thresholds and ramp steps,
+    [[maybe_unused]] double* const stp = thr + 64;                             //         valid from the unit's start to its pair step
+    auto value = [&](code_t c, [[maybe_unused]] int kbin) -> T {   // stored code -> float64, NaN / Inf -> 0 (profile0.py:62-66)
+        if constexpr (MODE == 1) {
+            // profile 1: dequantise (p1tools.py:44) / 2^(bits-1), times the threshold ramp at this bin (profile1.py:71-74)
+            const int32_t qv = (int32_t)c;
+            if (qv == 0) return 0.0;
+            const int hh = (threadIdx.x >> 5) & 1;
+            return (p1w_dequant((double)qv) / pw.scale) * p1w_spread(p1t, thr, stp, hh, kbin);
+        } else
         if constexpr (BITS == 32) {
             float f = u2f(wave_perm(c, psel));
 #ifdef FRAD_HOST_EMULATION
@@ -797,6 +1062,21 @@ k_p0_inv_wave(const unsigned char* __restrict__ payload, double* __restrict__ ou
         const bool lane0 = (l == 0);
         const long long next = ub + wave_next_unit(ctr);
         if constexpr (!PF) load_words(u, -1);
+        if constexpr (MODE == 1) {
+            // thresholds of this unit's frame(s): thr[b] = (e/2)^quant(tq[b]) (profile1.py:63), ramp steps (p1tools.py:35-41)
+            const long long ft = CC == 2 ? u : frame_of(u, h);
+            if (l < 27) {
+                const double t = (double)pw.tq_in[(ft * 27 + l) * CC + (CC == 2 ? h : 0)];
+                thr[h * 32 + l] = pow(2.718281828459045 / 2, p1w_quant(t));
+            }
+            team_sync<64>();
+            if (l < 27) {
+                double st = 0.0;
+                if (l < 26) { const int num = p1t.edge[l + 1] - p1t.edge[l]; if (num > 0) st = (thr[h * 32 + l + 1] - thr[h * 32 + l]) / (double)num; }
+                stp[h * 32 + l] = st;
+            }
+            team_sync<64>();
+        }
         // ---- inverse pair step: X[k], X[N-k], X[M-k], X[M+k] -> Z'[k], Z'[M-k] -----------------------
         cx<T> E[16], O[16];
         {
@@ -819,7 +1099,10 @@ k_p0_inv_wave(const unsigned char* __restrict__ payload, double* __restrict__ ou
             for (int s = 0; s < 16; ++s) {
                 if (s + 1 < 16) ptab_load(s + 1);
                 FRAD_FENCE();
-                const T xa = value(w[s][0]), xd = value(w[s][1]), xb = value(w[s][2]), xc = value(w[s][3]);
+                // bins of the four words (see load_words): k, N - k, M - k, M + k; lane 0 of job 0 borrows 1536 and 512
+                const int kq = wave_job_k(l, s);
+                const T xa = value(w[s][0], kq), xd = value(w[s][1], (s == 0 && lane0) ? 1536 : N - kq),
+                        xb = value(w[s][2], (s == 0 && lane0) ? 512 : M - kq), xc = value(w[s][3], M + kq);
                 if (s == 0) {
                     // lane 0: k = 0 (X[N] = 0, X[M] on both sides) and, from the two borrowed words, the self-paired k = 512
                     inv_pair(xa, lane0 ? 0.0 : xd, lane0 ? xc : xb, xc, ptab[0][0], ptab[0][1], zk[0], zm[0]);
@@ -839,6 +1122,7 @@ k_p0_inv_wave(const unsigned char* __restrict__ payload, double* __restrict__ ou
             }
         }
         FRAD_FENCE();
+        if constexpr (MODE == 1) team_sync<64>();              // thresholds read by every lane before the planes overwrite them
         // ---- inverse 16-point DFTs over m; the odd half takes conj(W_32^n) --------------------------
         dft<16, true>(E);
         FRAD_FENCE();
@@ -966,6 +1250,18 @@ k_p0_inv_wave(const unsigned char* __restrict__ payload, double* __restrict__ ou
         team_sync<64>();
         u = next;
     }
+}
+
+template <int CC, int BITS>
+__global__ void FRAD_WAVE_BOUNDS
+k_p0_inv_wave(const unsigned char* __restrict__ payload, double* __restrict__ out, const cx<double>* __restrict__ blob, Geom g) {
+    wave_inv_body<CC, BITS, 0>(payload, out, blob, g, P1None{});
+}
+// K8: q int32 [n_frames, 2048, C] (as `payload`, stride 2048 * C * 4 bytes) + pw.tq_in -> float64 PCM
+template <int CC>
+__global__ void FRAD_WAVE_BOUNDS
+k_p1_inv_wave(const unsigned char* __restrict__ q, double* __restrict__ out, const cx<double>* __restrict__ blob, Geom g, P1Wave pw) {
+    wave_inv_body<CC, 32, 1>(q, out, blob, g, pw);
 }
 
 }  // namespace frad
