@@ -319,7 +319,7 @@ def main():
                 "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": nbytes,
                 "avg_launch_ms": round(ms, 4)}
     ENC_NAME = "k_p0_fwd_wave<s16,C=2,32> (LDS-DMA load+to_f64+DCT-II 32x32+absmax+f32 cast+BE pack)"
-    DEC_NAME = "k_p0_inv_unit<PlanA10,32,C=2> (unpack+scrub+inverse DCT+f64 interleaved store)"
+    DEC_NAME = "k_p0_inv_wave<C=2,32> (unpack+scrub+inverse DCT pair step+32x32 IDFT+f64 interleaved store)"
     r_enc, r_dec = roof(ENC_NAME, enc_bytes, enc_ms), roof(DEC_NAME, dec_bytes, dec_ms)
     # HBM traffic per launch from the committed rocprofv3 PMC passes (profiles/, tools/profile_round.sh: FETCH_SIZE and
     # WRITE_SIZE in separate passes, FETCH_SIZE x2 as the gfx950 guide prescribes) -- only when that file was taken from

@@ -59,11 +59,14 @@ template <int NW> __device__ __forceinline__ void load_words(const unsigned char
         w[0] = *FRAD_GCPTR(uint32_t, p);
     }
 }
-template <int NW> __device__ __forceinline__ void store_words(unsigned char* p, const uint32_t (&w)[NW]) {
+// STREAM: nontemporal store.  Measured (profiles/r02_bench_extra.jsonl vs r01): it pays only where a wave's store
+// instruction covers whole contiguous lines (consecutive lanes, consecutive 16-byte pieces); for lane-strided pieces it
+// defeats the write combining in L2 and costs 20-35 %.
+template <int NW, bool STREAM = false> __device__ __forceinline__ void store_words(unsigned char* p, const uint32_t (&w)[NW]) {
 #pragma unroll
     for (int i = 0; i < NW / 4; ++i) {
         v4u v = {w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
-        FRAD_NT_STORE(v, FRAD_GPTR(v4u, p) + i);              // payload / PCM rows are written once: streaming store
+        if constexpr (STREAM) FRAD_NT_STORE(v, FRAD_GPTR(v4u, p) + i); else *(FRAD_GPTR(v4u, p) + i) = v;
     }
 }
 // element i (LG = log2 itemsize) of a little-endian word array
@@ -119,7 +122,7 @@ __device__ __forceinline__ void p4_pack_body(const unsigned char* __restrict__ p
             }
             uint32_t out[UB / 4];
             pack_unit<BITS>(codes, le, out);
-            store_words<UB / 4>(dst + u * UB, out);
+            store_words<UB / 4, BITS == 32>(dst + u * UB, out);
         };
         const long long step = (long long)bpf * blockDim.x;
         long long u = (long long)chunk * blockDim.x + threadIdx.x;
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(256) k_p4_unpack(const unsigned char* __restri
 #pragma unroll
         for (int i = 0; i < U / 2; ++i) {
             v2d v = {code_to_f64(codes[2 * i], BITS), code_to_f64(codes[2 * i + 1], BITS)};
-            FRAD_NT_STORE(v, FRAD_GPTR(v2d, dst + u * U) + i);
+            *(FRAD_GPTR(v2d, dst + u * U) + i) = v;
         }
     }
     if (chunk == 0)
@@ -285,7 +288,7 @@ __global__ void __launch_bounds__(256) k_p4_unpack_12b(const unsigned char* __re
             val[i] = code_to_f64(c, BITS);
         }
 #pragma unroll
-        for (int i = 0; i < V / 2; ++i) { v2d v = {val[2 * i], val[2 * i + 1]}; FRAD_NT_STORE(v, FRAD_GPTR(v2d, dst + u * V) + i); }
+        for (int i = 0; i < V / 2; ++i) { v2d v = {val[2 * i], val[2 * i + 1]}; *(FRAD_GPTR(v2d, dst + u * V) + i) = v; }
     };
     const long long step = (long long)bpf * blockDim.x;
     long long u = (long long)chunk * blockDim.x + threadIdx.x;
@@ -823,7 +826,7 @@ __device__ FRAD_NOINLINE void store_pcm_f64(int smem_off, double* __restrict__ o
                 if (++c == C) { c = 0; ++n; }
                 const double v1 = xslot<double, SH>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n);
                 v2d v = {v0, v1};
-                FRAD_NT_STORE(v, FRAD_GPTR(v2d, dst) + p);
+                *(FRAD_GPTR(v2d, dst) + p) = v;
             }
         } else {
             for (int e = threadIdx.x; e < NC; e += blockDim.x) {
@@ -1014,7 +1017,7 @@ __device__ FRAD_NOINLINE void store_pcm_group(int smem_off, double* __restrict__
         for (int q = threadIdx.x; q < N * half; q += blockDim.x) {
             const int n = q / half, j = (q - n * half) * 2, m = makhoul(n, N);
             v2d v = {xslot<double, SH>(smem, j, slots, m), xslot<double, SH>(smem, j + 1, slots, m)};
-            FRAD_NT_STORE(v, FRAD_GPTR(v2d, dst + (long long)n * C + c0 + j));
+            *FRAD_GPTR(v2d, dst + (long long)n * C + c0 + j) = v;
         }
         return;
     }

@@ -79,15 +79,15 @@ k_p0_inv_grp2(const unsigned char* __restrict__ payload, double* __restrict__ ou
         double* row = dst + (long long)n * C;
         if constexpr (CG >= 2) {
 #pragma unroll
-            for (int j = 0; j < CG; j += 2) { v2d v = {res[i][j], res[i][j + 1]}; FRAD_NT_STORE(v, FRAD_GPTR(v2d, row + j)); }
+            for (int j = 0; j < CG; j += 2) { v2d v = {res[i][j], res[i][j + 1]}; *FRAD_GPTR(v2d, row + j) = v; }
 #pragma unroll
             for (int j = 0; j < CG; j += 2) {
                 v2d v = {xslot<double, SH>(smem, j, SLOTS, m), xslot<double, SH>(smem, j + 1, SLOTS, m)};
-                FRAD_NT_STORE(v, FRAD_GPTR(v2d, row + CG + j));
+                *FRAD_GPTR(v2d, row + CG + j) = v;
             }
         } else {
             v2d v = {res[i][0], xslot<double, SH>(smem, 0, SLOTS, m)};
-            FRAD_NT_STORE(v, FRAD_GPTR(v2d, row));
+            *FRAD_GPTR(v2d, row) = v;
         }
     }
 }

@@ -31,6 +31,18 @@ class DecodeResult:
         self.crit = crit
 
 
+def _lossless_frame_len(nbytes: int, depth_idx: int, channels: int, header_fsize: int) -> int:
+    """Sample-frames a lossless payload holds.  The reference's profile0/4.digital never look at the header's fsize: they
+    unpack every stored value and reshape(-1, channels) (profile0.py:46-69, profile4.py:43-63), so the payload length
+    decides.  A length that is no whole number of sample-frames (the reference's reshape then raises) keeps the header
+    value and fails in the launch checks."""
+    bits = _LOSSLESS_DEPTHS[depth_idx] if depth_idx < len(_LOSSLESS_DEPTHS) else 0
+    if not bits or channels < 1:
+        return header_fsize
+    values = (nbytes * 2) // 3 if bits == 12 else (nbytes * 8) // bits
+    return values // channels if values and values % channels == 0 else header_fsize
+
+
 def _strip_ecc(frad: bytes, dsize: int, codesize: int) -> bytes:
     """tools/ecc.py:14-25 with repair off: drop the Reed-Solomon code bytes of every block."""
     block = dsize + codesize
@@ -51,6 +63,7 @@ class Decoder:
         self.buffer = b""
         self._data, self._pos = b"", 0
         self.overlap_fragment = np.array([])          # tail of the last compact frame, [L, C]
+        self.overlap_prog = 0                         # rows of the fragment already cross-faded (decoder.py:25, 36): persists across frames and calls
         self.fix_error = fix_error
         self.broken_frame = False
         self._bridge = bridge
@@ -121,7 +134,8 @@ class Decoder:
                 tl = struct.unpack(">I", raw[:4])[0]
                 t = p1tools.exp_golomb_rice_decode(raw[4:4 + tl])[:27 * channels]
                 q = p1tools.exp_golomb_rice_decode(raw[4 + tl:])[:fsize * channels]
-                ts[i, :t.size], qs[i, :q.size] = t, q
+                lim = np.iinfo(np.int32)                          # (only a corrupt stream holds values beyond int32: saturate, as the device coder does)
+                ts[i, :t.size], qs[i, :q.size] = np.clip(t, lim.min, lim.max), np.clip(q, lim.min, lim.max)
             pcm = self.bridge.p1_decode(qs.reshape(-1, fsize, channels), ts.reshape(-1, 27, channels), fsize, channels, bits, srate)
             for i in bad:
                 pcm[i] = 0.0
@@ -148,18 +162,17 @@ class Decoder:
         """decoder.py:28-46 verbatim semantics for the odd cases (fragment of another length)."""
         profile, fsize, channels, depth_idx, endian, srate, ratio = key
         out = []
-        prog = 0
         for frame in pcm:
             frame = frame.copy()
             L = len(self.overlap_fragment)
             if L:
                 w = 0.5 * (1 - np.cos(np.pi * np.arange(1, L + 1) / (L + 1)))
-                n = min(L - prog, len(frame))
-                i = np.arange(n) + prog
+                n = min(L - self.overlap_prog, len(frame))
+                i = np.arange(n) + self.overlap_prog
                 frame[:n] = frame[:n] * w[i, None] + self.overlap_fragment[i] * w[L - 1 - i, None]
-                prog += n
-            if L <= prog:
-                self.overlap_fragment, prog = np.array([]), 0
+                self.overlap_prog += n
+            if L <= self.overlap_prog:
+                self.overlap_fragment, self.overlap_prog = np.array([]), 0
                 if profile in profiles.COMPACT and ratio != 0:
                     cut = len(frame) * (ratio - 1) // ratio
                     self.overlap_fragment, frame = frame[cut:], frame[:cut]
@@ -209,9 +222,11 @@ class Decoder:
             frad = self._data[off:off + need]
             if a.ecc:
                 frad = _strip_ecc(frad, a.ecc_dsize, a.ecc_codesize)
-        key = (a.profile, a.fsize, a.channels, a.bit_depth_index, a.endian, a.srate, a.overlap_ratio)
+        nb = need if frad is None else len(frad)
+        fsize = a.fsize if a.profile == 1 else _lossless_frame_len(nb, a.bit_depth_index, a.channels, a.fsize)
+        key = (a.profile, fsize, a.channels, a.bit_depth_index, a.endian, a.srate, a.overlap_ratio)
         a.clear()
-        return key, (frad, off, need if frad is None else len(frad))
+        return key, (frad, off, nb)
 
     def process(self, stream: bytes) -> DecodeResult:
         """Parse as the reference does (decoder.py:51-108) but decode runs of like frames in one launch each."""
@@ -331,8 +346,10 @@ class Decoder:
                 frad = self._data[p_off:p_off + p_len]
                 if ecc:
                     frad = _strip_ecc(frad, dsize, csize)
-            key = (profile, fsize, ch, depth, bool(le), srate, ratio)
-            append(key, (frad, p_off, p_len if frad is None else len(frad)))
+            nb = p_len if frad is None else len(frad)
+            n_eff = fsize if profile == 1 else _lossless_frame_len(nb, depth, ch, fsize)
+            key = (profile, n_eff, ch, depth, bool(le), srate, ratio)
+            append(key, (frad, p_off, nb))
             self._scanned_frames += 1
             self._pos = p_off + p_len
             self.broken_frame = False
@@ -343,6 +360,6 @@ class Decoder:
 
     def flush(self) -> DecodeResult:
         ret = self.overlap_fragment
-        self.overlap_fragment = np.array([])
+        self.overlap_fragment = np.array([])                  # (overlap_prog is left alone, as in the reference)
         self.asfh.clear()
         return self._narrow(DecodeResult([ret], self.asfh.srate, 0, False))

@@ -240,3 +240,17 @@ def test_decoder_output_format(kind, fmt):
             want = fo.from_f64(plain, dt).astype(dt)
         assert got.dtype == dt and got.shape == want.shape, (p["profile"], got.dtype, got.shape, want.shape)
         assert got.tobytes() == want.tobytes(), p["profile"]
+
+
+def test_lossless_frame_length_comes_from_the_payload(kind):
+    """profile0/4.digital ignore the header's fsize: they unpack what the payload holds (profile4.py:43-63).  A header
+    that lies about fsize must decode like the reference."""
+    pcm = synth.to_pcm(synth.harmonic_mix(3000, 2, 48000, seed=6), "s16le").tobytes()
+    p = dict(profile=4, srate=48000, channels=2, bits=16, frame_size=1024, pcm_format="s16le")
+    stream = bytearray(fo.encode_stream(pcm, **p))
+    at = bytes(stream).find(b"\xff\xd0\xd2\x98")
+    assert int.from_bytes(stream[at + 24:at + 28], "big") == 1024
+    stream[at + 24:at + 28] = (777).to_bytes(4, "big")          # first frame's header now claims 777 sample-frames
+    want = fo.decode_stream(bytes(stream))
+    got, frames = _decode(kind, bytes(stream), 4096, 2)
+    assert got.shape == want.shape == (3000, 2) and np.array_equal(got, want)
