@@ -21,6 +21,7 @@
 //                  run of zero bits ends the stream; a code cut short by the end of the buffer is read from the bits there).
 #include "frad_common.hpp"
 #include "../../include/frad_hip.h"
+#include <cstdlib>
 
 namespace frad {
 namespace {
@@ -321,13 +322,14 @@ __device__ __forceinline__ void decode_stream_wave(const unsigned char* p, long 
 
 __global__ void __launch_bounds__(64) k_gol_decode(const unsigned char* __restrict__ bodies, const long long* __restrict__ offsets, long long n_frames,
                                                    long long nq, long long ntq, int32_t* __restrict__ q, int32_t* __restrict__ tq,
-                                                   int32_t* __restrict__ status) {
+                                                   int32_t* __restrict__ status, const int32_t* __restrict__ todo) {
     const long long f = (long long)blockIdx.x * 64 + threadIdx.x;
     const bool live = f < n_frames;                           // spare lanes of the last wave keep the rounds uniform
     const unsigned char* b = live ? bodies + offsets[f] : bodies;
     long long len = live ? offsets[f + 1] - offsets[f] : 0;
     long long tlen = 0;
-    if (live && status) status[f] = len < 4 ? 1 : 0;          // no length word: nothing decodable (the host treats it as broken)
+    const int mine = live ? (todo ? todo[f] : 3) : 0;         // streams the wave-per-frame kernel left to this one (bit 0: tq, bit 1: q)
+    if (live && status && !todo) status[f] = len < 4 ? 1 : 0;          // no length word: nothing decodable (the host treats it as broken)
     if (len >= 4) {
         tlen = ((long long)b[0] << 24) | ((long long)b[1] << 16) | ((long long)b[2] << 8) | (long long)b[3];
         if (tlen > len - 4) tlen = len - 4;                   // frad[:thresbytes] past the end: Python slicing clamps
@@ -336,8 +338,160 @@ __global__ void __launch_bounds__(64) k_gol_decode(const unsigned char* __restri
         const unsigned char* sp = which ? b + 4 + tlen : b + 4;
         const long long sl = which ? len - 4 - tlen : tlen;
         int32_t* dst = which ? q + (live ? f * nq : 0) : tq + (live ? f * ntq : 0);
-        decode_stream_wave(sp, sl, dst, live ? (which ? nq : ntq) : 0);
+        decode_stream_wave(sp, sl, dst, (mine >> which) & 1 ? (which ? nq : ntq) : 0);
     }
+}
+
+// ---- decode, one WAVE per frame (the fast path) ----------------------------------------------------------------------
+// The sequential dependency of a prefix code is broken in two phases.  The stream sits in LDS; lane i owns the bits
+// [i CHB, (i+1) CHB).  Phase 1, all lanes at once: walking its chunk backwards, a lane computes for every bit position p
+// "if a code started here, how many codes start before my chunk ends and at which offset does the next chunk get
+// entered" -- entry(p) = entry(p + 2 z(p) + k + 1) + 1 code, a ring of the last 64 positions is all it needs -- so that
+// at the end the ring holds that map for the first 64 bits of the chunk.  Phase 2: 64 dependent look-ups chain the maps
+// (entry offset and output index of every chunk).  Phase 3, all lanes at once: each decodes its own ~1/64 of the codes.
+// Codes longer than 64 bits, k > 30 and streams beyond the LDS budget are left to the lane-per-frame kernel (`todo`).
+constexpr int GW_WORDS = 6144;             // most stream words a wave holds in LDS (24 KiB); the launch sizes it for 16 bits per value
+constexpr int GW_E = 64;                   // longest code / entry range handled here
+constexpr int GW_PITCH = 65;               // ring pitch in words (odd: lanes hit different banks)
+constexpr int gw_lds(int wmax) { return (wmax + 2) * 4 + 64 * GW_PITCH * 4; }
+constexpr uint32_t GW_END = 255, GW_LONG = 254;
+
+__device__ __forceinline__ uint32_t gw_bits(const uint32_t* words, long long pos, int n) {      // n in [1, 32], MSB first
+    const long long w = pos >> 5; const int off = (int)(pos & 31);
+    const u64 two = ((u64)words[w] << 32) | (u64)words[w + 1];
+    return (uint32_t)((two << off) >> (64 - n));
+}
+
+// one stream of the calling WAVE's frame; false = leave it to the slow kernel (nothing written)
+__device__ __forceinline__ bool decode_stream_2phase(const unsigned char* p, long long len, int32_t* __restrict__ out, long long cap, int wmax) {
+    FRAD_DYN_SMEM(smem_);
+    uint32_t* words = reinterpret_cast<uint32_t*>(smem_);
+    uint32_t* ring = words + wmax + 2 + (threadIdx.x & 63) * GW_PITCH;
+    const uint32_t* rings = words + wmax + 2;
+    const int lane = threadIdx.x & 63;
+    const long long nbytes = len >= 1 ? len - 1 : 0;
+    long long total = 0;
+    if (nbytes > 0 && cap > 0) {
+        const int k = (int)p[0];
+        const unsigned char* bits = p + 1;
+        const int lead = (int)(reinterpret_cast<uintptr_t>(bits) & 3);
+        const unsigned char* a0 = bits - lead;
+        const long long nwords = (lead + nbytes + 3) >> 2;
+        if (nwords > wmax || k > 30) return false;
+        const long long T = (long long)lead * 8 + nbytes * 8;    // end of the stream in word space; it starts at bit lead * 8
+        FRAD_LDS_BARRIER();                                       // the previous stream's phases are done with the LDS
+        for (long long w = lane; w < nwords + 2; w += 64) {
+            uint32_t v = 0;
+            if (w < nwords) {
+                v = bswap32(*FRAD_GCPTR(uint32_t, a0 + 4 * w));
+                if (w == 0 && lead) v &= 0xffffffffu >> (8 * lead);          // bytes before the stream
+                const long long hi = (w + 1) * 32;
+                if (hi > T) v = (T - w * 32) > 0 ? v & ~(0xffffffffu >> (int)(T - w * 32)) : 0u;      // bytes after it
+            }
+            words[w] = v;
+        }
+        FRAD_LDS_BARRIER();
+        long long chb = (T + 63) / 64;
+        if (chb < GW_E) chb = GW_E;
+        const long long nch = (T + chb - 1) / chb;
+        const long long cs = lane * chb, ce = cs + chb < T ? cs + chb : T;
+        // ---- phase 1: the entry map of this lane's chunk ---------------------------------------------------
+        if (lane < nch) {
+            // zero run at the chunk's end (it continues into the next chunk): scan ahead, at most GW_E + 1 bits
+            int z = 0; bool inf = false;
+            {
+                long long q = ce;
+                while (z <= GW_E) {
+                    if (q >= T) { inf = true; break; }
+                    const int n = (int)(T - q < 32 ? T - q : 32);
+                    const uint32_t v = gw_bits(words, q, n) << (32 - n);
+                    if (v == 0) { z += n; q += n; continue; }
+                    z += __builtin_clz(v); break;
+                }
+            }
+            uint32_t cur = 0;
+            for (long long pp = ce - 1; pp >= cs; --pp) {
+                if ((pp & 31) == 31 || pp == ce - 1) cur = words[pp >> 5];
+                const bool one = (cur >> (31 - (int)(pp & 31))) & 1u;
+                if (one) { z = 0; inf = false; } else if (z <= GW_E) ++z;
+                uint32_t e;
+                if (inf) e = GW_END;                                              // zeros to the end: no code starts here
+                else {
+                    const int clen = 2 * z + k + 1;
+                    const long long nx = pp + clen;
+                    if (clen > GW_E) e = GW_LONG;
+                    else if (nx >= T) e = (1u << 8) | GW_END;                     // the stream's last code (maybe cut short)
+                    else if (nx >= ce) e = (1u << 8) | (uint32_t)(nx - ce);
+                    else {
+                        const uint32_t t = ring[(int)((nx - cs) & 63)];
+                        e = (t & 255u) == GW_LONG ? GW_LONG : t + (1u << 8);
+                    }
+                }
+                ring[(int)((pp - cs) & 63)] = e;
+            }
+        }
+        FRAD_LDS_BARRIER();
+        // ---- phase 2: chain the maps (every lane walks the same chain and keeps its own link) -----------------
+        long long my_base = 0, my_cnt = 0; int my_entry = 0;
+        {
+            int e = lead * 8; long long base = 0; bool ended = false, bad = false;
+            for (long long i = 0; i < nch; ++i) {
+                if (!ended) {
+                    const uint32_t t = rings[(int)i * GW_PITCH + e];
+                    const uint32_t x = t & 255u;
+                    if (x == GW_LONG) { bad = true; break; }
+                    if (i == lane) { my_base = base; my_entry = e; my_cnt = (long long)(t >> 8); }
+                    base += (long long)(t >> 8);
+                    if (x == GW_END) ended = true; else e = (int)x;
+                }
+            }
+            if (bad) return false;                                                // (uniform: every lane read the same words)
+            total = base < cap ? base : cap;
+        }
+        // ---- phase 3: every lane decodes the codes that start in its chunk ------------------------------------
+        if (lane < nch) {                                             // exactly the codes phase 1 counted for this chunk
+            long long pos = cs + my_entry, idx = my_base;
+            for (long long c = 0; c < my_cnt && idx < cap; ++c) {
+                // zeros up to the '1' (phase 1 guarantees there is one before T and that the code is <= 64 bits)
+                int z = 0;
+                for (;;) {
+                    const int n = (int)(T - pos < 32 ? T - pos : 32);
+                    if (n <= 0) break;                                          // (cannot happen: phase 1 saw the '1'; never spin)
+                    const uint32_t v = gw_bits(words, pos, n) << (32 - n);
+                    if (v == 0) { z += n; pos += n; continue; }
+                    const int c = __builtin_clz(v); z += c; pos += c; break;
+                }
+                long long want = z + k + 1;
+                if (want > T - pos) want = T - pos;                               // cut short by the end of the buffer
+                if (want <= 0) break;
+                u64 val = 0;
+                if (want > 32) { val = gw_bits(words, pos, (int)(want - 32)); pos += want - 32; want = 32; }
+                val = (val << want) | gw_bits(words, pos, (int)want);
+                pos += want;
+                const long long n = (long long)val - (1LL << k);
+                out[idx++] = sat32((n & 1) ? (n + 1) >> 1 : -(n >> 1));
+            }
+        }
+    }
+    for (long long j = total + lane; j < cap; j += 64) out[j] = 0;
+    return true;
+}
+
+__global__ void __launch_bounds__(64) k_gol_decode_wave(const unsigned char* __restrict__ bodies, const long long* __restrict__ offsets,
+                                                        long long nq, long long ntq, int32_t* __restrict__ q, int32_t* __restrict__ tq,
+                                                        int32_t* __restrict__ status, int32_t* __restrict__ todo, int wmax) {
+    const long long f = blockIdx.x;
+    const unsigned char* b = bodies + offsets[f];
+    long long len = offsets[f + 1] - offsets[f];
+    long long tlen = 0;
+    if (threadIdx.x == 0 && status) status[f] = len < 4 ? 1 : 0;
+    if (len >= 4) {
+        tlen = ((long long)b[0] << 24) | ((long long)b[1] << 16) | ((long long)b[2] << 8) | (long long)b[3];
+        if (tlen > len - 4) tlen = len - 4;
+    } else len = 4;
+    const bool ok_t = decode_stream_2phase(b + 4, tlen, tq + f * ntq, ntq, wmax);
+    const bool ok_q = decode_stream_2phase(b + 4 + tlen, len - 4 - tlen, q + f * nq, nq, wmax);
+    if (threadIdx.x == 0) todo[f] = (ok_t ? 0 : 1) | (ok_q ? 0 : 2);
 }
 
 thread_local int g_gol_hip = 0;
@@ -391,9 +545,24 @@ int frad_p1_golomb_decode(const void* bodies, const int64_t* offsets, int64_t n_
     if (n_frames == 0) return FRAD_OK;
     if (!bodies || !offsets || !q || !tq) return FRAD_E_INVALID;
     const long long blocks = ((long long)n_frames + 63) / 64;
-    if (blocks > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
-    hipLaunchKernelGGL(k_gol_decode, dim3((unsigned)blocks), dim3(64), DEC_LDS, static_cast<hipStream_t>(stream), static_cast<const unsigned char*>(bodies),
-                       reinterpret_cast<const long long*>(offsets), (long long)n_frames, (long long)N * C, 27LL * C, q, tq, status);
+    if (n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static const bool no_wave = [] { const char* e = std::getenv("FRAD_TUNE_GOLOMB_LANE"); return e && e[0] == '1'; }();
+    int32_t* todo = nullptr;
+    if (!no_wave) {
+        // fast path: one wave per frame; what it cannot take (codes > 64 bits, k > 30, streams beyond its LDS) is marked in
+        // `todo` and decoded by the lane-per-frame kernel behind it
+        if (hipMallocAsync(reinterpret_cast<void**>(&todo), sizeof(int32_t) * (size_t)n_frames, s) != hipSuccess) return FRAD_E_NOMEM;
+        // LDS budget: 16 bits per coefficient on average (a frame above that goes to the slow kernel): at N C = 4096 that is
+        // 8.4 KiB of stream + 16.6 KiB of entry maps per wave, six waves per CU
+        long long wmax = ((long long)N * C * 16) / 32 + 64;
+        if (wmax > GW_WORDS) wmax = GW_WORDS;
+        hipLaunchKernelGGL(k_gol_decode_wave, dim3((unsigned)n_frames), dim3(64), gw_lds((int)wmax), s, static_cast<const unsigned char*>(bodies),
+                           reinterpret_cast<const long long*>(offsets), (long long)N * C, 27LL * C, q, tq, status, todo, (int)wmax);
+    }
+    hipLaunchKernelGGL(k_gol_decode, dim3((unsigned)blocks), dim3(64), DEC_LDS, s, static_cast<const unsigned char*>(bodies),
+                       reinterpret_cast<const long long*>(offsets), (long long)n_frames, (long long)N * C, 27LL * C, q, tq, status, todo);
+    if (todo) (void)hipFreeAsync(todo, s);
     GOLCHK(hipGetLastError());
     return FRAD_OK;
 }

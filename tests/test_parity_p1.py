@@ -216,3 +216,37 @@ def test_golomb_random_round_trip_and_decoder_end_conditions(be):
         wt, wq = np.clip(wt, -2 ** 31, 2 ** 31 - 1)[:27 * C], np.clip(wq, -2 ** 31, 2 ** 31 - 1)[:N * C]
         assert np.array_equal(dt[i].reshape(-1), _pad(wt.astype(np.int64), 27 * C)), i
         assert np.array_equal(dq[i].reshape(-1), _pad(wq.astype(np.int64), N * C)), i
+
+
+def test_golomb_decoder_on_damaged_streams(be):
+    """Random bit flips and zero runs inside valid bodies: long codes (> 64 bits), spurious early ends, values beyond
+    int32 -- the wave-per-frame decoder must hand what it cannot take to the lane-per-frame one, and both must agree with
+    the reference decoder's semantics (p1tools.py:62-74; values outside int32 saturate here)."""
+    rng = np.random.default_rng(99)
+    N, C = (640, 2) if be.name == "emu" else (2048, 2)
+    q = np.rint(rng.laplace(0, 8.0, (1, N, C))).astype(np.int32)
+    tq = rng.integers(0, 40, (1, 27, C)).astype(np.int32)
+    body = bytearray(be.golomb_encode(q, tq)[0])
+    tl = int.from_bytes(body[:4], "big")
+    variants = []
+    for i in range(12 if be.name == "emu" else 60):
+        b = bytearray(body)
+        kind = i % 4
+        at = int(rng.integers(5 + tl + 1, len(b) - 1))
+        if kind == 0:
+            b[at] ^= 1 << int(rng.integers(0, 8))                                  # one flipped bit
+        elif kind == 1:
+            n = int(rng.integers(3, 40)); b[at:at + n] = bytes(min(n, len(b) - at))   # a run of zero bytes: one very long code
+        elif kind == 2:
+            b[4 + tl] = int(rng.integers(0, 40))                                   # another k for the coefficient stream
+        else:
+            for _ in range(5):
+                b[int(rng.integers(5 + tl + 1, len(b)))] = int(rng.integers(0, 256))
+        variants.append(bytes(b))
+    dq, dt, st = be.golomb_decode(variants, N, C)
+    lim = np.iinfo(np.int32)
+    for i, b in enumerate(variants):
+        wq = fo.golomb_decode(b[4 + tl:])[:N * C]
+        wq = np.array([max(lim.min, min(lim.max, int(v))) for v in wq], dtype=np.int64)
+        assert np.array_equal(dq[i].reshape(-1), _pad(wq, N * C)), (i, i % 4)
+        assert np.array_equal(dt[i], tq[0]), i
