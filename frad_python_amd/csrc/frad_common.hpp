@@ -389,4 +389,37 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v) {
     return wave_allreduce_u64(v, [](u64 a, u64 b) { return b > a ? b : a; });
 }
 
+// ---------------------------------------------------------------------------------------------
+// decoder output conversion: one float64 sample -> the bytes of PCM format (KIND, log2 itemsize), little-endian in the
+// returned word.  from_f64(pcm, fmt).astype(fmt) of the reference's caller (backend/pcmformat.py:49-62, src/decoder.py:23);
+// integer overflow as numpy yields it on x86-64 (cvttsd2si), see frad_epilogue.hip.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t x86_cvtt32(double v) {      // cvttsd2si r32
+    return (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : (int32_t)0x80000000u;
+}
+__device__ __forceinline__ long long x86_cvtt64(double v) {    // cvttsd2si r64
+    return (v >= -9223372036854775808.0 && v < 9223372036854775808.0) ? (long long)v : (long long)0x8000000000000000ull;
+}
+
+// one float64 sample -> the element's bytes (little-endian in the returned word; `be` formats are swapped by the caller)
+// `raw`: the reference's big-endian-integer quirk on the way out -- pcm_format == np.int16 is False for '>i2', so
+// from_f64 returns the float64 samples unscaled and the caller's .astype(fmt) truncates those (FRAD_RAW_BE_INTS)
+template <int KIND, int LGS>
+__device__ __forceinline__ u64 from_f64_bits(double x, bool raw) {
+    if constexpr (KIND == 2) {
+        if constexpr (LGS == 1) return f64_to_f16_bits(x);
+        else if constexpr (LGS == 2) return f2u((float)x);
+        else return d2u(x);
+    } else {
+        constexpr int w = 8 << LGS;
+        const double scale = u2d((u64)(1023 + (w - 1)) << 52);          // 2^(w-1), exact
+        const double v = raw ? x : (KIND == 0 ? x + 1.0 : x) * scale;
+        if constexpr (LGS <= 1) return (u64)((uint32_t)x86_cvtt32(v) & ((1u << w) - 1u));
+        else if constexpr (LGS == 2) return KIND == 1 ? (u64)(uint32_t)x86_cvtt32(v) : (u64)(uint32_t)x86_cvtt64(v);
+        else {
+            if constexpr (KIND == 1) return (u64)x86_cvtt64(v);
+            else return v >= 9223372036854775808.0 ? (u64)x86_cvtt64(v - 9223372036854775808.0) + 0x8000000000000000ull : (u64)x86_cvtt64(v);
+        }
+    }
+}
 }  // namespace frad

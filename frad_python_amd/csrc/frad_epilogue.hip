@@ -13,39 +13,12 @@
 #include "frad_launch.hpp"
 #include "../../include/frad_hip.h"
 
+#include <cmath>
 #include <cstring>
 
 namespace frad {
 namespace {
 
-__device__ __forceinline__ int32_t x86_cvtt32(double v) {      // cvttsd2si r32
-    return (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : (int32_t)0x80000000u;
-}
-__device__ __forceinline__ long long x86_cvtt64(double v) {    // cvttsd2si r64
-    return (v >= -9223372036854775808.0 && v < 9223372036854775808.0) ? (long long)v : (long long)0x8000000000000000ull;
-}
-
-// one float64 sample -> the element's bytes (little-endian in the returned word; `be` formats are swapped by the caller)
-// `raw`: the reference's big-endian-integer quirk on the way out -- pcm_format == np.int16 is False for '>i2', so
-// from_f64 returns the float64 samples unscaled and the caller's .astype(fmt) truncates those (FRAD_RAW_BE_INTS)
-template <int KIND, int LGS>
-__device__ __forceinline__ u64 from_f64_bits(double x, bool raw) {
-    if constexpr (KIND == 2) {
-        if constexpr (LGS == 1) return f64_to_f16_bits(x);
-        else if constexpr (LGS == 2) return f2u((float)x);
-        else return d2u(x);
-    } else {
-        constexpr int w = 8 << LGS;
-        const double scale = u2d((u64)(1023 + (w - 1)) << 52);          // 2^(w-1), exact
-        const double v = raw ? x : (KIND == 0 ? x + 1.0 : x) * scale;
-        if constexpr (LGS <= 1) return (u64)((uint32_t)x86_cvtt32(v) & ((1u << w) - 1u));
-        else if constexpr (LGS == 2) return KIND == 1 ? (u64)(uint32_t)x86_cvtt32(v) : (u64)(uint32_t)x86_cvtt64(v);
-        else {
-            if constexpr (KIND == 1) return (u64)x86_cvtt64(v);
-            else return v >= 9223372036854775808.0 ? (u64)x86_cvtt64(v - 9223372036854775808.0) + 0x8000000000000000ull : (u64)x86_cvtt64(v);
-        }
-    }
-}
 template <int LGS> __device__ __forceinline__ u64 swap_elem(u64 b) {
     if constexpr (LGS == 1) return bswap16((uint32_t)b);
     else if constexpr (LGS == 2) return bswap32((uint32_t)b);
@@ -121,6 +94,22 @@ bool valid_out_dtype(int d) {
     return !(kind == 2 && lg == 0) && !(lg == 0 && be);
 }
 
+// exp(-i pi p / q), the generator the wave table blob is built with (same values as frad_hip.hip's unit_neg)
+void epi_unit_neg(long long p, long long q, long double& re, long double& im) {
+    const long double PI = 3.14159265358979323846264338327950288419716939937510L;
+    long long r = p % (2 * q); if (r < 0) r += 2 * q;
+    const long long h = q / 2;
+    const int quad = (int)(r / h);
+    const long long rem = r % h;
+    long double c, sn;
+    if (4 * rem <= q) { c = cosl(PI * (long double)rem / (long double)q); sn = sinl(PI * (long double)rem / (long double)q); }
+    else { c = sinl(PI * (long double)(h - rem) / (long double)q); sn = cosl(PI * (long double)(h - rem) / (long double)q); }
+    if (rem == 0) { c = 1.0L; sn = 0.0L; }
+    long double C, S;
+    switch (quad) { case 0: C = c; S = sn; break; case 1: C = -sn; S = c; break; case 2: C = -c; S = -sn; break; default: C = sn; S = -c; }
+    re = C; im = -S;
+}
+
 thread_local int g_epi_hip = 0;
 #define EPICHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_epi_hip = (int)e_; return FRAD_E_HIP; } } while (0)
 
@@ -164,8 +153,8 @@ int frad_p4_digital_pcm(const void* payload, int64_t payload_stride, int64_t n_f
     return FRAD_OK;
 }
 
-// profile 0 / 1: the transform kernels write float64; the narrowing pass follows on the same stream (the staging buffer
-// is stream-ordered scratch).  TODO(next): fuse the cast into the N = 2048 wave kernel's output stage.
+// profile 0 / 1: N = 2048 stereo at 16 / 32-bit storage converts inside the wave kernel's output stage; elsewhere the
+// transform kernels write float64 and the narrowing pass follows on the same stream (stream-ordered scratch).
 int frad_p0_digital_pcm(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C, int32_t bits,
                         uint32_t flags, int32_t out_dtype, void* pcm_out, void* stream) {
     if (!valid_out_dtype(out_dtype)) return FRAD_E_INVALID;
@@ -173,6 +162,17 @@ int frad_p0_digital_pcm(const void* payload, int64_t payload_stride, int64_t n_f
     if (n_frames < 0 || N < 1 || C < 1) return FRAD_E_INVALID;
     if (n_frames == 0) return FRAD_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (payload && pcm_out && (bits == 16 || bits == 32) && payload_stride >= (int64_t)frad_payload_bytes(N, C, bits)) {
+        // N = 2048 stereo: the conversion is fused into the wave kernel's output stage (one pass, 4-6 B per sample out)
+        Geom g{};
+        g.n_frames = n_frames; g.frame_stride = N; g.payload_stride = payload_stride; g.N = N; g.C = C; g.bits = bits;
+        g.le = (flags & FRAD_LITTLE_ENDIAN) ? 1 : 0; g.dtype = FRAD_PCM_F64LE; g.fpb = 1; g.n_valid = N; g.cg = C;
+        const int ai = ((reinterpret_cast<uintptr_t>(payload) & 15) == 0 && payload_stride % 16 == 0) ? 1 : 0;
+        if (launch_p0_inv_wave_pcm(s, static_cast<const unsigned char*>(payload), pcm_out, g, ai, out_dtype, epi_unit_neg)) {
+            EPICHK(hipGetLastError());
+            return FRAD_OK;
+        }
+    }
     Scratch ws(s);
     const size_t n = (size_t)n_frames * N * C;
     if (hipMallocAsync(&ws.p, n * 8, s) != hipSuccess) return FRAD_E_NOMEM;

@@ -88,6 +88,7 @@ int launch_p0_inv_wave(hipStream_t s, const unsigned char* pay, double* out, con
 struct P1Wave;
 int launch_p1_inv_wave(hipStream_t s, const int32_t* q, double* out, const Geom& g, const P1Wave& pw, unit_root_fn unit);
 int launch_p1_fwd_wave(int lg, hipStream_t s, const unsigned char* pcm, int32_t* q, const Geom& g, const P1Wave& pw, int aligned_in, unit_root_fn unit);
+int launch_p0_inv_wave_pcm(hipStream_t s, const unsigned char* pay, void* out, const Geom& g, int aligned_in, int out_dtype, unit_root_fn unit);
 void wave_blob_build(std::vector<unsigned char>& bytes, unit_root_fn unit);
 void wave_clear();
 // workspace path of last resort (frad_global.hip): frames that no LDS-resident kernel can hold run through HBM buffers

@@ -42,6 +42,14 @@ for bits in (32, 24, 16):
     o = torch.empty((F, N, C), dtype=torch.float64, device=dev)
     out.append(line(f"p4 encode s16->b{bits}", S * (2 + bits / 8), timeit(lambda: core.analogue_batch(4, pcm, "s16le", F, N, C, bits, check_overflow=False, out=enc.payload, absmax=enc.absmax)), S))
     out.append(line(f"p4 decode b{bits}->f64", S * (bits / 8 + 8), timeit(lambda: core.digital_batch(4, enc.payload, F, N, C, bits, out=o)), S))
+# profile 0 decode with the from_f64 conversion fused into the wave kernel (frad_p0_digital_pcm): B_out = itemsize
+enc0 = core.analogue_batch(0, pcm, "s16le", F, N, C, 32, check_overflow=False)
+for ofmt, osz in (("s16le", 2), ("f32le", 4)):
+    ob = torch.empty(F * N * C * osz, dtype=torch.uint8, device=dev)
+    out.append(line(f"p0 decode b32->{ofmt} (conversion fused, cfg-2 size)", S * (4 + osz),
+                    timeit(lambda: core.digital_batch(0, enc0.payload, F, N, C, 32, out=ob, out_format=ofmt)), S))
+o0 = torch.empty((F, N, C), dtype=torch.float64, device=dev)
+out.append(line("p0 decode b32->f64 (cfg-2 size, for comparison)", S * 12, timeit(lambda: core.digital_batch(0, enc0.payload, F, N, C, 32, out=o0)), S))
 # cfg 4: 60 s of 192 kHz 8-channel f32, N = 4096, 32 bit
 F, N, C = 2812, 4096, 8
 pcm4 = (torch.rand((F * N, C), generator=g, device=dev) * 1.8 - 0.9).to(torch.float32)
