@@ -117,8 +117,7 @@ __global__ void __launch_bounds__(256) k_g_p1_quant(const double* __restrict__ x
     for (int k = threadIdx.x; k < N; k += blockDim.x) {
         const double x = tb.f32 ? (double)(float)X[k] : X[k];
         const double div = p1_spread(l, 0, k);
-        const double m = (div == 0.0) ? 0.0 * x : x / div;
-        q[(f0 + f) * (long long)N * C + (long long)k * C + c] = (int32_t)rint(p1_quant(m * tb.scale));
+        q[(f0 + f) * (long long)N * C + (long long)k * C + c] = p1w_quantise(x, div, tb.scale);
     }
 }
 

@@ -141,8 +141,26 @@ bool p1_fast_fits(FastCfg& c, int N, int C) {
     return (size_t)c.fpb * C * M * 16 + p1_scratch_bytes(c.fpb * C, N) <= 160 * 1024;
 }
 
+// |q|^(1/0.75) for q = 0 .. 255 (p1tools.py:44 dequant), long double -> correctly rounded double; one table per device
+std::map<int, double*> g_deq;
+const double* deq_table() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_band_mu);
+    auto it = g_deq.find(dev);
+    if (it != g_deq.end()) return it->second;
+    double host[256];
+    for (int a = 0; a < 256; ++a) host[a] = (double)powl((long double)a, (long double)(1.0 / 0.75));
+    double* d = nullptr;
+    if (hipMalloc(&d, sizeof host) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, host, sizeof host, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    g_deq[dev] = d;
+    return d;
+}
+
 P1Wave wave_tables(const P1Tables& tb, int N) {
     P1Wave pw{};
+    pw.deq = nullptr;
     for (int i = 0; i < 28; ++i) pw.edge[i] = tb.edge[i] < N ? tb.edge[i] : N;
     for (int i = 0; i < 27; ++i) pw.floor_[i] = tb.floor_[i];
     pw.scale = tb.scale; pw.loss = tb.loss; pw.nb_used = tb.nb_used; pw.band_of = tb.band_of; pw.tq_in = nullptr; pw.tq_out = nullptr;
@@ -179,6 +197,8 @@ void p1_clear() {                                            // frad_plan_clear:
     std::lock_guard<std::mutex> lk(g_band_mu);
     for (auto& kv : g_band) (void)hipFree(kv.second);
     g_band.clear();
+    for (auto& kv : g_deq) (void)hipFree(kv.second);
+    g_deq.clear();
 }
 }  // namespace frad
 
@@ -274,6 +294,7 @@ int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32
     {
         P1Wave pw = wave_tables(tb, N);
         pw.tq_in = tq;
+        pw.deq = deq_table();
         if (launch_p1_inv_wave(s, q, pcm_out, g, pw, p1_unit_neg)) { P1CHK(hipGetLastError()); return FRAD_OK; }
     }
     FastCfg c = fast_cfg(N, C, false);

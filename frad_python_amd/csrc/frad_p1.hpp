@@ -147,8 +147,7 @@ __device__ FRAD_NOINLINE void p1_quantise(int smem_off, int scratch_off, int slo
         double x = xslot<double, SH>(smem, cf, slots, k);
         if (f32) x = (double)(float)x;
         const double div = p1_spread(l, cf, k);
-        const double m = (div == 0.0) ? 0.0 * x : x / div;                // x / inf keeps the sign of x
-        q[(f0 + fl) * (long long)N * C + (long long)k * C + c0 + j] = (int32_t)rint(p1_quant(m * scale));
+        q[(f0 + fl) * (long long)N * C + (long long)k * C + c0 + j] = p1w_quantise(x, div, scale);   // float32 where it decides, else exact
     }
 }
 

@@ -47,7 +47,7 @@ int launch_p1_fwd_wave(int lg, hipStream_t s, const unsigned char* pcm, int32_t*
 // K8
 int launch_p1_inv_wave(hipStream_t s, const int32_t* q, double* out, const Geom& g, const P1Wave& pw, unit_root_fn unit) {
     if (wave_off() || p1_wave_off() || g.N != 2048 || (g.C != 1 && g.C != 2)) return 0;
-    if ((reinterpret_cast<uintptr_t>(out) & 15) || (reinterpret_cast<uintptr_t>(q) & 3) || pw.edge[26] < g.N) return 0;
+    if ((reinterpret_cast<uintptr_t>(out) & 15) || (reinterpret_cast<uintptr_t>(q) & 3) || pw.edge[26] < g.N || pw.deq == nullptr) return 0;
     const void* blob = wave_blob_get(unit);
     if (blob == nullptr) return 0;
     const int grid = wave_grid(g.C == 2 ? g.n_frames : (g.n_frames + 1) / 2);

@@ -206,22 +206,24 @@ struct P1Wave {
     double scale, loss;          // 2^(bits-1); max(|loss_level|, 0.125)
     int nb_used;                 // bands before the first empty one
     const unsigned char* band_of;// device table [N]: band of bin k (0..25), 255 = beyond the last band start
+    const double* deq;           // device table [256]: a^(1/0.75) for a = 0 .. 255 (p1tools.py:44), correctly rounded
     const int32_t* tq_in;        // K8: [n_frames, 27, C]
     int32_t* tq_out;             // K7: [n_frames, 27, C]
 };
 struct P1None {};
-constexpr int kP1BlockBytes = 2048 + 32 * 4 + 32 * 8;        // band_of[2048] | edge[32] | floor[32], after the work counter
+constexpr int kP1BlockBytes = 2048 + 32 * 4 + 32 * 8 + 256 * 8;   // band_of[2048] | edge[32] | floor[32] | deq[256], after the work counter
 constexpr int kWaveLdsBytesP1 = kWaveLdsBytes + 16 + kP1BlockBytes;
-struct P1Lds2 { const unsigned char* band; const int* edge; const double* floor_; };
+struct P1Lds2 { const unsigned char* band; const int* edge; const double* floor_; const double* deq; };
 __device__ __forceinline__ P1Lds2 p1w_lds(unsigned char* smem) {
     unsigned char* b = smem + kWaveLdsBytes + 16;
-    return {b, reinterpret_cast<const int*>(b + 2048), reinterpret_cast<const double*>(b + 2048 + 128)};
+    return {b, reinterpret_cast<const int*>(b + 2048), reinterpret_cast<const double*>(b + 2048 + 128), reinterpret_cast<const double*>(b + 2048 + 128 + 256)};
 }
 __device__ __forceinline__ void p1w_tables_to_lds(unsigned char* smem, const P1Wave& pw) {
     unsigned char* b = smem + kWaveLdsBytes + 16;
     for (int i = threadIdx.x; i < 512; i += blockDim.x) reinterpret_cast<uint32_t*>(b)[i] = reinterpret_cast<const uint32_t*>(pw.band_of)[i];
     if (threadIdx.x < 28) reinterpret_cast<int*>(b + 2048)[threadIdx.x] = pw.edge[threadIdx.x];
     if (threadIdx.x < 27) reinterpret_cast<double*>(b + 2048 + 128)[threadIdx.x] = pw.floor_[threadIdx.x];
+    if (threadIdx.x < 256 && pw.deq != nullptr) reinterpret_cast<double*>(b + 2048 + 128 + 256)[threadIdx.x] = pw.deq[threadIdx.x];
 }
 // per-wave scratch at the start of the wave's buffer: thr[2][32] | stp[2][32] | acc[2][32] doubles (index h * 32 + band)
 __device__ __forceinline__ double p1w_spread(const P1Lds2& t, const double* thr, const double* stp, int h, int k) {
@@ -238,6 +240,34 @@ __device__ __forceinline__ double p1w_quant(double x) {        // sign(x) |x|^0.
     return copysign(r * sqrt(r), x) * (a != 0.0);
 }
 __device__ __forceinline__ double p1w_dequant(double x) { const double a = fabs(x); return copysign(a * cbrt(a), x) * (a != 0.0); }
+
+// (int) round(sign(m) |m * scale|^0.75) with m = x / div -- the per-bin quantiser of profile1.py:27-36 -- decided in
+// float32 whenever that is safe: the float32 value of |.|^0.75 carries a relative error below 1.5e-6 (two conversions,
+// a reciprocal, two square roots, four products), so unless it lies within that distance of a half-integer it rounds to
+// the same integer as the float64 value; the rare undecided bin (about y x 3e-6 of them) takes the exact path.  The
+// result is therefore identical to the float64 arithmetic's, at a quarter of its instructions.
+__device__ __forceinline__ float p1w_sqrtf(float v) {
+#ifdef FRAD_HOST_EMULATION
+    return sqrtf(v);
+#else
+    return __builtin_amdgcn_sqrtf(v);
+#endif
+}
+__device__ __forceinline__ int32_t p1w_quantise(double x, double div, double scale) {
+    const float xf = (float)x, df = (float)div;
+    if (div == 0.0) return 0;                                 // x / inf -> +-0 -> 0
+    const float mf = fabsf(xf) / df * (float)scale;           // div > 0: thresholds are non-negative
+    if (mf < 1e30f) {                                         // (false for NaN: those take the exact path)
+        const float r = p1w_sqrtf(mf), yf = r * p1w_sqrtf(r);
+        const float fr = yf - floorf(yf);
+        if (fabsf(fr - 0.5f) > yf * 3e-6f + 1e-6f) {
+            const int32_t qa = (int32_t)rintf(yf);
+            return xf < 0.0f ? -qa : qa;
+        }
+    }
+    const double m = x / div;
+    return (int32_t)rint(p1w_quant(m * scale));
+}
 // Band energy -> masking threshold of one band (p1tools.py:18-33).  `f32`: numpy's types on float32 coefficients --
 // mean, sqrt and the 0.8 power stay float32, and the product with the loss level does too when the signal term wins.
 __device__ __forceinline__ double p1_band_threshold(double energy, int bins, double floor_, double loss, int f32) {
@@ -363,12 +393,16 @@ __device__ __forceinline__ void wave_p1_quantise(const cx<T> (&E)[16], const cx<
             const T v2 = valid ? v * v : 0.0;
             int blo, bhi;
             seg_bands(s, cls, blo, bhi);
+#ifdef FRAD_X_P1_NOSUM
+            accreg += v2; (void)blo; (void)bhi; (void)kb;
+#else
             for (int b = blo; b <= bhi; ++b) {
                 const int ea = wave_uniform_int(p1t.edge[b]), eb = wave_uniform_int(p1t.edge[b + 1]);
                 double s0, s1;
                 half_wave_sum_f64((kb >= ea && kb < eb) ? v2 : 0.0, s0, s1);
                 accreg += (l == b) ? (h ? s1 : s0) : 0.0;
             }
+#endif
         }
         FRAD_FENCE();
     }
@@ -391,12 +425,18 @@ __device__ __forceinline__ void wave_p1_quantise(const cx<T> (&E)[16], const cx<
     if (l < 27) {
         const int b = l, bins = p1t.edge[b + 1] - p1t.edge[b];
         double t = 0.0;
+#ifdef FRAD_X_P1_NOPOW
+        t = accreg + 1.0; (void)bins;
+        thr[h * 32 + b] = t;
+        if (live) pw.tq_out[(f * 27 + b) * CC + c] = (int32_t)t;
+#else
         if (b < pw.nb_used) t = p1_band_threshold(accreg, bins, p1t.floor_[b], pw.loss, 0);
         thr[h * 32 + b] = t;
         if (live) {
             const double v = log(t > 1.0 ? t : 1.0) / log(2.718281828459045 / 2);
             pw.tq_out[(f * 27 + b) * CC + c] = (int32_t)rint(copysign(pow(fabs(v), 1.0 / 0.75), v));
         }
+#endif
     }
     team_sync<64>();
     if (l < 27) {
@@ -407,10 +447,7 @@ __device__ __forceinline__ void wave_p1_quantise(const cx<T> (&E)[16], const cx<
     team_sync<64>();
     // ---- pass B: per-bin divide + power-law quantiser (profile1.py:27-36), 256 contiguous bytes per store ----------
     int32_t* qf = q + (live ? f : 0) * (long long)N * CC + c;
-    auto quant_div = [&](T x, double div) -> int32_t {
-        const double m = (div == 0.0) ? 0.0 * x : x / div;      // x / inf keeps the sign of x
-        return (int32_t)rint(p1w_quant(m * pw.scale));
-    };
+    auto quant_div = [&](T x, double div) -> int32_t { return p1w_quantise(x, div, pw.scale); };
     // threshold ramp at bin kb of band b (np.linspace without its end point; numpy's branch for a vanishing step)
     auto ramp = [&](int b, int ea, int eb, int kb) -> double {
         const double t0 = thr[h * 32 + b], st = stp[h * 32 + b], i = (double)(kb - ea);
@@ -434,12 +471,20 @@ __device__ __forceinline__ void wave_p1_quantise(const cx<T> (&E)[16], const cx<
             int blo, bhi;
             seg_bands(s, cls, blo, bhi);
             double div = 0.0;                                    // bins beyond the last band start divide by 0 -> 0
+#ifdef FRAD_X_P1_NORAMP
+            div = thr[h * 32 + (blo & 15)] + (double)bhi;
+#else
             for (int b = blo; b <= bhi; ++b) {
                 const int ea = wave_uniform_int(p1t.edge[b]), eb = wave_uniform_int(p1t.edge[b + 1]);
                 const double d = ramp(b, ea, eb, kb);
                 div = (kb >= ea && kb < eb) ? d : div;
             }
+#endif
+#ifdef FRAD_X_P1_NOQUANT
+            const int32_t qv = (int32_t)(x[cls] * div);
+#else
             const int32_t qv = quant_div(x[cls], div);
+#endif
             if (valid && live) *FRAD_GPTR(int32_t, qf + (long long)kb * CC) = qv;
         }
         FRAD_FENCE();
@@ -1031,7 +1076,10 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
             const int32_t qv = (int32_t)c;
             if (qv == 0) return 0.0;
             const int hh = (threadIdx.x >> 5) & 1;
-            return (p1w_dequant((double)qv) / pw.scale) * p1w_spread(p1t, thr, stp, hh, kbin);
+            const int32_t aq = qv < 0 ? -qv : qv;
+            // |q|^(1/0.75): small magnitudes (nearly all of them) from the LDS table, the rest through cbrt
+            const double dq = (uint32_t)aq < 256u ? (qv < 0 ? -p1t.deq[aq] : p1t.deq[aq]) : p1w_dequant((double)qv);
+            return (dq / pw.scale) * p1w_spread(p1t, thr, stp, hh, kbin);
         } else
         if constexpr (BITS == 32) {
             float f = u2f(wave_perm(c, psel));

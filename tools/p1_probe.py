@@ -4,7 +4,9 @@ FRAD_TUNE_NO_WAVE_P1=1 selects the one-shot kernels for comparison."""
 import json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from frad_python_amd import core
+from frad_python_amd import core, _lib
+if os.environ.get("FRAD_PROBE_LIB"):                     # diagnostic builds of libfrad_hip.so (kernel ablations)
+    _lib.LIB_PATH = os.environ["FRAD_PROBE_LIB"]
 dev = torch.device("cuda:0")
 def timeit(fn, reps=20, warm=5):
     for _ in range(warm): fn()
