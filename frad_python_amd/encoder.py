@@ -20,6 +20,22 @@ _LOSSLESS_DEPTHS = (12, 16, 24, 32, 48, 64)
 _P1_DEPTHS = (8, 12, 16, 24, 32, 48, 64)
 
 
+_POOL = None
+
+
+def _map_zlib(fn, items: list) -> list:
+    """deflate / inflate of a batch's frames on a small thread pool: zlib releases the GIL, the frames are independent and
+    the results are the bytes the serial loop would give (profile1.py:50, :59)"""
+    global _POOL
+    if len(items) < 8:
+        return [fn(b) for b in items]
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4))
+    return list(_POOL.map(fn, items, chunksize=max(1, len(items) // 64)))
+
+
 class EncodeResult:
     def __init__(self, buf: bytes, samples: int):
         self.buf = buf
@@ -80,9 +96,10 @@ class Encoder:
             on_device = getattr(self.bridge, "p1_encode_bodies", None)
             if on_device is not None:
                 # quantiser and Exp-Golomb-Rice coder on the device; the host only deflates (profile1.py:50) and frames
-                for body in on_device(pcm, self.pcm_format_name, n_frames, N, C, bits, compact.get_valid_srate(self.srate),
-                                      self.loss_level, hop, n_valid):
-                    out.append(self._emit(self._deflate(body), _P1_DEPTHS.index(bits), n_valid))
+                bodies = on_device(pcm, self.pcm_format_name, n_frames, N, C, bits, compact.get_valid_srate(self.srate),
+                                   self.loss_level, hop, n_valid)
+                for frad in _map_zlib(self._deflate, bodies):
+                    out.append(self._emit(frad, _P1_DEPTHS.index(bits), n_valid))
                 return b"".join(out)
             q, tq = self.bridge.p1_encode(pcm, self.pcm_format_name, n_frames, N, C, bits, compact.get_valid_srate(self.srate),
                                           self.loss_level, hop, n_valid)
