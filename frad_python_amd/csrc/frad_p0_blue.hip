@@ -42,7 +42,7 @@ template <int LOG2L, int LG>
 __global__ void __launch_bounds__(1024) k_p0_fwd_blue(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload,
                                                       double* absmax, const cx<double>* __restrict__ tw,
                                                       const cx<double>* __restrict__ wconj, const cx<double>* __restrict__ bhat,
-                                                      const cx<double>* __restrict__ pw, Geom g, int aligned_out) {
+                                                      const cx<double>* __restrict__ pw, const cx<double>* __restrict__ pw2, Geom g, int aligned_out) {
     constexpr int L = 1 << LOG2L, TEAM = Plan<LOG2L>::TEAM, SH = Plan<LOG2L>::SH;
     FRAD_DYN_SMEM(smem);
     const int N = g.N, C = g.C, cg = g.cg;
@@ -55,6 +55,47 @@ __global__ void __launch_bounds__(1024) k_p0_fwd_blue(const unsigned char* __res
     const unsigned char* src = pcm + ((f * g.frame_stride * C) << LG);
     const double inv_n = 1.0 / (double)N;
     const bool whole = g.in_mode != 0;                       // X area holds all C channels: one whole-frame pack at the end
+    if (g.cc_fast) {
+        // Channel PAIRS (whole frames, even C): the two real sequences of channels 2p, 2p+1 ride one complex Bluestein
+        // convolution as v0 + i v1 -- half the FFT work and half the LDS -- and are told apart afterwards by the Hermitian
+        // symmetry of a real sequence's DFT: with u_k = conj(w_k) z_k,  V0 = (u_k + conj(u_{N-k})) / 2,
+        // V1 = (u_k - conj(u_{N-k})) / 2i;  pw2[k] = e^{-i pi k / 2N} w_{N-k} (pw2[0] = 1) is the second half's table.
+        const int P = C / 2;
+        const double inv_2n = 0.5 * inv_n;
+        for (int p0 = 0; p0 < P; p0 += cg) {
+            const int cgn = P - p0 < cg ? P - p0 : cg;
+            for (int q = threadIdx.x; q < N * cgn; q += blockDim.x) {
+                const int n = q / cgn, j = q - n * cgn, c = 2 * (p0 + j);
+                double v0 = 0.0, v1 = 0.0;
+                if (n < g.n_valid) {
+                    const unsigned char* e = src + (((long long)n * C + c) << LG);
+                    v0 = cvt_pcm<double>(load_raw(e, LG), g.dtype, g.raw_be);
+                    v1 = cvt_pcm<double>(load_raw(e + (1 << LG), LG), g.dtype, g.raw_be);
+                }
+                const int slot = makhoul(n, N);
+                const cx<double> w = wconj[slot];
+                bufs[(long long)j * L + phys<double, SH>(slot)] = cx<double>{v0 * w.x - v1 * w.y, v0 * w.y + v1 * w.x};
+            }
+            for (int q = threadIdx.x; q < (L - N) * cg; q += blockDim.x) {
+                const int sl = q / cg, j = q - sl * cg;
+                bufs[(long long)j * L + phys<double, SH>(N + sl)] = cx<double>{0.0, 0.0};
+            }
+            __syncthreads();
+            blue_convolve<LOG2L>(buf, t, tw, bhat);
+            if (cf < cgn) {
+                double* X0 = X + (long long)(2 * (p0 + cf)) * N;
+                for (int k = t; k < N; k += TEAM) {
+                    const cx<double> z = buf[phys<double, SH>(k)], z2 = buf[phys<double, SH>(k ? N - k : 0)];
+                    const cx<double> A = cmul(z, pw[k]), B = cmul(cx<double>{z2.x, -z2.y}, pw2[k]);
+                    X0[k] = (A.x + B.x) * inv_2n;
+                    X0[N + k] = (A.y - B.y) * inv_2n;
+                }
+            }
+            __syncthreads();
+        }
+        pack_out_any<double, -1>(xoff, payload, absmax, g, f, 1, N, aligned_out != 0);
+        return;
+    }
     for (int c0 = 0; c0 < C; c0 += cg) {
         const int cgn = C - c0 < cg ? C - c0 : cg;
         {                                                                    // a[slot] = v[slot] conj(w_slot)
@@ -119,6 +160,38 @@ __global__ void __launch_bounds__(1024) k_p0_inv_blue(const unsigned char* __res
     if (whole) unpack_in_any<-1>(payload, xoff, g, f, 1, N, aligned_in != 0);
     __syncthreads();
     const int half = (N + 1) / 2;                            // slots [0, half) hold the even time samples
+    if (g.cc_fast) {
+        // channel pairs: DFT(conj(A0) + i conj(A1)) = N (v0 + i v1) -- each A is Hermitian, so each transform is real
+        const int P = C / 2;
+        for (int p0 = 0; p0 < P; p0 += cg) {
+            const int cgn = P - p0 < cg ? P - p0 : cg;
+            for (int q = threadIdx.x; q < N * cgn; q += blockDim.x) {
+                const int k = q / cgn, j = q - k * cgn;
+                const double* X0 = X + (long long)(2 * (p0 + j)) * N;
+                const double* X1 = X0 + N;
+                const cx<double> a = {X0[k] - (k > 0 ? X1[N - k] : 0.0), (k > 0 ? X0[N - k] : 0.0) + X1[k]};
+                bufs[(long long)j * L + phys<double, SH>(k)] = cmul(a, pw[k]);
+            }
+            for (int q = threadIdx.x; q < (L - N) * cg; q += blockDim.x) {
+                const int sl = q / cg, j = q - sl * cg;
+                bufs[(long long)j * L + phys<double, SH>(N + sl)] = cx<double>{0.0, 0.0};
+            }
+            __syncthreads();                                  // (every X of this pair group has been read)
+            blue_convolve<LOG2L>(buf, t, tw, bhat);
+            if (cf < cgn) {
+                double* x0 = X + (long long)(2 * (p0 + cf)) * N;
+                for (int n = t; n < N; n += TEAM) {
+                    const cx<double> z = buf[phys<double, SH>(n)], w = wconj[n];
+                    const int time = n < half ? 2 * n : 2 * (N - 1 - n) + 1;
+                    x0[time] = z.x * w.x - z.y * w.y;
+                    x0[N + time] = z.x * w.y + z.y * w.x;
+                }
+            }
+            __syncthreads();
+        }
+        store_pcm_f64<-1, false>(xoff, out, g, f, 1, N);
+        return;
+    }
     for (int c0 = 0; c0 < C; c0 += cg) {
         const int cgn = C - c0 < cg ? C - c0 : cg;
         if (!whole) {
@@ -172,7 +245,7 @@ void unit_ld(long long p, long long q, ld& re, ld& im) {
     re = sign * c; im = -sign * s;
 }
 
-struct BlueTable { cx<double>* wconj = nullptr; cx<double>* bhat = nullptr; cx<double>* pw = nullptr; int log2l = 0; };
+struct BlueTable { cx<double>* wconj = nullptr; cx<double>* bhat = nullptr; cx<double>* pw = nullptr; cx<double>* pw2 = nullptr; int log2l = 0; };
 std::mutex g_mu;
 std::map<std::pair<int, int>, BlueTable> g_blue;             // (device, N)
 thread_local int g_last = 0;
@@ -216,11 +289,11 @@ int get_blue(int N, int log2l, BlueTable& out) {
     auto it = g_blue.find(key);
     if (it != g_blue.end()) { out = it->second; return FRAD_OK; }
     if (g_blue.size() >= 64) {                               // bounded cache of odd frame lengths
-        for (auto& kv : g_blue) { (void)hipFree(kv.second.wconj); (void)hipFree(kv.second.bhat); (void)hipFree(kv.second.pw); }
+        for (auto& kv : g_blue) { (void)hipFree(kv.second.wconj); (void)hipFree(kv.second.bhat); (void)hipFree(kv.second.pw); (void)hipFree(kv.second.pw2); }
         g_blue.clear();
     }
     const int L = 1 << log2l;
-    std::vector<cx<double>> wc((size_t)N), pw((size_t)N), bh((size_t)L);
+    std::vector<cx<double>> wc((size_t)N), pw((size_t)N), pw2((size_t)N), bh((size_t)L);
     std::vector<ld> br((size_t)L, 0.0L), bi((size_t)L, 0.0L);
     for (long long n = 0; n < N; ++n) {
         const long long r = (n * n) % (2LL * N);
@@ -230,6 +303,10 @@ int get_blue(int N, int log2l, BlueTable& out) {
         if (n > 0) { br[(size_t)(L - n)] = re; bi[(size_t)(L - n)] = -im; }
         unit_ld(2 * r + n, 2LL * N, re, im);                 // conj(w_k) exp(-i pi k / 2N)
         pw[(size_t)n] = cx<double>{(double)re, (double)im};
+        // channel pairs: exp(-i pi k / 2N) w_{N-k} = exp(+i pi (2 (N-k)^2 - k) / 2N); k = 0 pairs with itself (w_0 = 1)
+        const long long m = n == 0 ? 0 : (((long long)N - n) * ((long long)N - n)) % (2LL * N);
+        unit_ld(n - 2 * m, 2LL * N, re, im);
+        pw2[(size_t)n] = cx<double>{(double)re, (double)im};
     }
     host_fft(br, bi);
     for (int k = 0; k < L; ++k) bh[(size_t)k] = cx<double>{(double)(br[(size_t)k] / (ld)L), (double)(bi[(size_t)k] / (ld)L)};
@@ -237,11 +314,12 @@ int get_blue(int N, int log2l, BlueTable& out) {
     int rc = upload(wc, &t.wconj); if (rc != FRAD_OK) return rc;
     rc = upload(bh, &t.bhat); if (rc != FRAD_OK) return rc;
     rc = upload(pw, &t.pw); if (rc != FRAD_OK) return rc;
+    rc = upload(pw2, &t.pw2); if (rc != FRAD_OK) return rc;
     g_blue[key] = t; out = t;
     return FRAD_OK;
 }
 
-struct BlueCfg { bool ok = false; int log2l = 0, cg = 0, threads = 0, whole = 0; size_t lds = 0; };
+struct BlueCfg { bool ok = false; int log2l = 0, cg = 0, threads = 0, whole = 0, paired = 0; size_t lds = 0; };
 BlueCfg blue_cfg(int N, int C, int bits, bool fwd) {
     BlueCfg c;
     if (N < 96 || N > 4096) return c;                        // tiny frames: the direct product is cheaper
@@ -259,7 +337,10 @@ BlueCfg blue_cfg(int N, int C, int bits, bool fwd) {
         cg = (long long)(kLds / (per + (size_t)N * 8));
         if (fwd && bits == 12 && (C & 1)) return c;          // packing: 12-bit pairs must not straddle groups (reads may)
     }
-    if (cg > C) cg = C;
+    static const bool no_pairs = [] { const char* e = tune("FRAD_TUNE_BLUE_NO_PAIRS"); return e && e[0] == '1'; }();
+    c.paired = (c.whole && (C & 1) == 0 && !no_pairs) ? 1 : 0;   // two channels per complex transform
+    const long long need = c.paired ? C / 2 : C;
+    if (cg > need) cg = need;
     if (cg * team > 1024) cg = 1024 / team;
     if (!c.whole && fwd && bits == 12) cg &= ~1LL;
     if (cg < 1) return c;
@@ -272,7 +353,7 @@ template <int LOG2L>
 void go_fwd(int lg, const BlueCfg& c, dim3 grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* am,
             const cx<double>* tw, const BlueTable& t, const Geom& g, int ao) {
 #define GO(LGV) do { allow_lds(k_p0_fwd_blue<LOG2L, LGV>, c.lds); \
-        hipLaunchKernelGGL((k_p0_fwd_blue<LOG2L, LGV>), grid, dim3(c.threads), c.lds, s, pcm, pay, am, tw, t.wconj, t.bhat, t.pw, g, ao); } while (0)
+        hipLaunchKernelGGL((k_p0_fwd_blue<LOG2L, LGV>), grid, dim3(c.threads), c.lds, s, pcm, pay, am, tw, t.wconj, t.bhat, t.pw, t.pw2, g, ao); } while (0)
     switch (lg) { case 0: GO(0); break; case 1: GO(1); break; case 2: GO(2); break; default: GO(3); break; }
 #undef GO
 }
@@ -306,7 +387,7 @@ int blue_prepare(int N) {
 
 void blue_clear() {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (auto& kv : g_blue) { (void)hipFree(kv.second.wconj); (void)hipFree(kv.second.bhat); (void)hipFree(kv.second.pw); }
+    for (auto& kv : g_blue) { (void)hipFree(kv.second.wconj); (void)hipFree(kv.second.bhat); (void)hipFree(kv.second.pw); (void)hipFree(kv.second.pw2); }
     g_blue.clear();
 }
 
@@ -317,7 +398,7 @@ int launch_p0_fwd_blue(int lg, hipStream_t s, const unsigned char* pcm, unsigned
     const int r = tables_for(g.N, g.C, g.bits, true, c, t, &tw);
     if (r <= 0) return r;
     if (absmax) BCHK(hipMemsetAsync(absmax, 0, sizeof(double) * (size_t)g.n_frames, s));       // atomicMax target
-    g.cg = c.cg; g.fpb = 1; g.in_mode = c.whole;
+    g.cg = c.cg; g.fpb = 1; g.in_mode = c.whole; g.cc_fast = c.paired;
     dim3 grid((unsigned)g.n_frames);
     switch (c.log2l) {
         case 8: go_fwd<8>(lg, c, grid, s, pcm, pay, absmax, tw, t, g, aligned_out); break;
@@ -335,7 +416,7 @@ int launch_p0_inv_blue(hipStream_t s, const unsigned char* pay, double* out, Geo
     BlueCfg c; BlueTable t; const cx<double>* tw = nullptr;
     const int r = tables_for(g.N, g.C, g.bits, false, c, t, &tw);
     if (r <= 0) return r;
-    g.cg = c.cg; g.fpb = 1; g.in_mode = c.whole;
+    g.cg = c.cg; g.fpb = 1; g.in_mode = c.whole; g.cc_fast = c.paired;
     dim3 grid((unsigned)g.n_frames);
     switch (c.log2l) {
         case 8: go_inv<8>(c, grid, s, pay, out, tw, t, g, aligned_in); break;
