@@ -232,6 +232,8 @@ class Decoder:
 
     def process(self, stream: bytes) -> DecodeResult:
         """Parse as the reference does (decoder.py:51-108) but decode runs of like frames in one launch each."""
+        if not isinstance(stream, (bytes, bytearray)):
+            stream = bytes(stream)                              # memoryview and friends: the parser searches with bytes.find
         self._data, self._pos = (self.buffer + stream) if self.buffer else stream, 0
         try:
             res = self._process(len(stream) == 0)
