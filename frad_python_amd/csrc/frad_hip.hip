@@ -401,9 +401,13 @@ int frad_p0_analogue_checked(const void* pcm, int32_t pcm_dtype, int64_t n_frame
         dim3 grid((unsigned)((n_frames + c.fpb - 1) / c.fpb));
         if (!launch_p0_fwd_pers(f32, lg, c, s, in, out, absmax, tb, g, ao)) {
             if (absmax) HIPCHK(hipMemsetAsync(absmax, 0, sizeof(double) * (size_t)n_frames, s));   // atomicMax target
-            rc = f32 ? launch_p0_fwd_f32(lg, c, grid, s, in, out, absmax, tb, g, ai, ao)
-                     : launch_p0_fwd_f64(lg, c, grid, s, in, out, absmax, tb, g, ai, ao);
-            if (rc != FRAD_OK) return rc;
+            if (!f32 && c.cg < C && launch_p0_fwd_grp2(lg, c, s, in, out, absmax, tb, g, ai, ao)) {
+                // two channel groups with whole-row I/O took it (frad_p0_fwd_grp2.hip)
+            } else {
+                rc = f32 ? launch_p0_fwd_f32(lg, c, grid, s, in, out, absmax, tb, g, ai, ao)
+                         : launch_p0_fwd_f64(lg, c, grid, s, in, out, absmax, tb, g, ai, ao);
+                if (rc != FRAD_OK) return rc;
+            }
         }
     } else {
         if (!f32) {                                          // any N in O(N log N): Bluestein over the power-of-two FFT

@@ -68,7 +68,9 @@ size_t pers_blob_build(int log2m, bool f32, int which, std::vector<unsigned char
 int launch_p0_fwd_pers(bool f32, int lg, const FastCfg& c, hipStream_t s, const unsigned char* pcm, unsigned char* pay,
                        double* absmax, const Tables& tb, Geom g, int aligned_out);
 int launch_p0_inv_pers(const FastCfg& c, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb, Geom g);
-// two-pass whole-row decode of frames with C = 2 * cg channels (frad_p0_inv_grp2.hip): 1 = launched, 0 = not applicable
+// two-pass whole-row encode / decode of frames with C = 2 * cg channels (frad_p0_fwd_grp2.hip, frad_p0_inv_grp2.hip): 1 = launched, 0 = not applicable
+int launch_p0_fwd_grp2(int lg, const FastCfg& c, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* absmax,
+                       const Tables& tb, const Geom& g, int aligned_in, int aligned_out);
 int launch_p0_inv_grp2(const FastCfg& c, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb, const Geom& g);
 
 
