@@ -317,3 +317,22 @@ def test_golden_g1_vectors(be):
         assert pay[0].tobytes().hex() == c["hex"]
         dec = be.digital(4, pay, 1, c["n"], 1, c["bits"], c["le"])
         assert dec[0].astype("<f8").tobytes().hex() == c["decoded_hex"]
+
+
+@pytest.mark.parametrize("fmt,bits,le", [("s16le", 16, False), ("s16le", 32, True), ("s32le", 64, False), ("u16le", 32, False)])
+def test_p0_two_channel_groups_whole_rows(be, fmt, bits, le):
+    """Frames whose float64 channels need exactly two passes through a CU's LDS (C = 2 x channel group): the whole-row
+    kernels k_p0_fwd_grp2 / k_p0_inv_grp2 (8 channels at N = 4096 on the GPU; 16 channels at N = 2048 fits the emulator)."""
+    N, C, F = (2048, 16, 2) if be.name == "emu" else (4096, 8, 5)
+    rng = np.random.default_rng(N + bits)
+    raw = synth.to_pcm(rng.uniform(-1, 1, (F * N, C)), fmt)
+    pay, am = be.analogue(0, raw, fmt, F, N, C, bits, le)
+    ref = oracle_frames(fo, 0, raw, fmt, F, N, C, bits, le)
+    mism = 0
+    for f in range(F):
+        mism += check_p0_payload(pay[f], ref[f][0], bits, le, fmt, N)
+        assert abs(am[f] - ref[f][2]) <= 8 * EPS64 * np.log2(N) * ref[f][2]
+    assert mism <= max(2, 1e-5 * F * N * C), mism
+    dec = be.digital(0, np.stack([r[0] for r in ref]), F, N, C, bits, le)
+    for f in range(F):
+        assert np.max(np.abs(dec[f] - ref[f][1])) <= 16 * EPS64 * np.log2(N) * max(1.0, np.max(np.abs(ref[f][1])))
