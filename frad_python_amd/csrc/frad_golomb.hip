@@ -145,20 +145,19 @@ __global__ void __launch_bounds__(GT) k_gol_encode(const int32_t* __restrict__ q
     }
 }
 
-// offsets[0] = 0, offsets[i + 1] = offsets[i] + nbytes[i]; one block
+// offsets[0] = 0, offsets[i + 1] = offsets[i] + nbytes[i]; one block: every thread sums a contiguous run of rows, one
+// block scan over the 256 run totals, then every thread writes its run's prefix sums
 __global__ void __launch_bounds__(GT) k_rows_scan(const long long* __restrict__ nbytes, long long n, long long* __restrict__ offsets) {
     FRAD_DYN_SMEM(smem);
     long long* tmp = reinterpret_cast<long long*>(smem);
-    long long carry = 0;
+    const long long per = (n + GT - 1) / GT;
+    const long long a = (long long)threadIdx.x * per, e = a + per < n ? a + per : n;
+    long long mine = 0;
+    for (long long i = a; i < e; ++i) mine += nbytes[i];
+    long long total;
+    long long run = block_scan(mine, tmp, &total) - mine;        // sum of all rows before this thread's run
     if (threadIdx.x == 0) offsets[0] = 0;
-    for (long long i0 = 0; i0 < n; i0 += GT) {
-        const long long i = i0 + threadIdx.x;
-        const long long v = i < n ? nbytes[i] : 0;
-        long long total;
-        const long long inc = block_scan(v, tmp, &total);
-        if (i < n) offsets[i + 1] = carry + inc;
-        carry += total;
-    }
+    for (long long i = a; i < e; ++i) { run += nbytes[i]; offsets[i + 1] = run; }
 }
 __global__ void __launch_bounds__(GT) k_rows_gather(const unsigned char* __restrict__ rows, long long stride, const long long* __restrict__ offsets,
                                                     unsigned char* __restrict__ out) {

@@ -1086,7 +1086,7 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
 #ifdef FRAD_HOST_EMULATION
             if (!std::isfinite(f)) f = 0.0f;
 #else
-            if (__builtin_amdgcn_classf(f, 0x203)) f = 0.0f;   // signalling / quiet NaN, -Inf, +Inf
+            if (__builtin_amdgcn_classf(f, 0x207)) f = 0.0f;   // class mask: bit 0 signalling NaN, 1 quiet NaN, 2 -Inf, 9 +Inf
 #endif
             return (T)f;
         } else if constexpr (BITS == 16) {
@@ -1094,7 +1094,7 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
 #ifdef FRAD_HOST_EMULATION
             if (!std::isfinite(f)) f = 0.0f;
 #else
-            if (__builtin_amdgcn_classf(f, 0x203)) f = 0.0f;
+            if (__builtin_amdgcn_classf(f, 0x207)) f = 0.0f;
 #endif
             return (T)f;
         } else {

@@ -336,3 +336,23 @@ def test_p0_two_channel_groups_whole_rows(be, fmt, bits, le):
     dec = be.digital(0, np.stack([r[0] for r in ref]), F, N, C, bits, le)
     for f in range(F):
         assert np.max(np.abs(dec[f] - ref[f][1])) <= 16 * EPS64 * np.log2(N) * max(1.0, np.max(np.abs(ref[f][1])))
+
+
+@pytest.mark.parametrize("bits", [16, 32])
+def test_p0_decode_scrubs_both_infinities(be, bits):
+    """profile0.digital zeroes NaN, +Inf AND -Inf before the inverse transform (profile0.py:66).  Found by a long fuzz run:
+    the N = 2048 wave decode kernel's float-class mask lacked -Inf (unscaled big-endian integers overflow a 16-bit
+    payload in both directions)."""
+    N, C, F = 2048, 2, 2
+    rng = np.random.default_rng(bits)
+    x = rng.uniform(-1, 1, (F, N * C))
+    store = np.float16 if bits == 16 else np.float32
+    pay = np.zeros((F, N * C), store)
+    pay[:] = x.astype(store)
+    for f in range(F):                                         # sprinkle the specials over both frames
+        pay[f, 3::97] = np.inf; pay[f, 5::89] = -np.inf; pay[f, 7::83] = np.nan
+    raw = np.ascontiguousarray(pay.astype(pay.dtype.newbyteorder(">"))).view(np.uint8).reshape(F, -1)
+    want = np.stack([fo.p0_digital(raw[f].tobytes(), fo.DEPTHS.index(bits), C, False) for f in range(F)])
+    got = be.digital(0, raw, F, N, C, bits, False)
+    assert np.all(np.isfinite(got))
+    assert np.max(np.abs(got - want)) <= 16 * EPS64 * np.log2(N) * max(1.0, np.max(np.abs(want)))
