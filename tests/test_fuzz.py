@@ -106,3 +106,41 @@ def test_random_profile1_geometries_against_oracle():
         ok += 1
     print("p1 fuzz:", rounds, "rounds", {"ok": ok, "refused": 0})
     assert ok == rounds
+
+
+def test_random_entropy_stage_and_output_conversion():
+    """Round-2 entry points under random geometry: Exp-Golomb-Rice coder / decoder against the oracle's coder (any legal
+    compact size, 1-6 channels, value ranges from all-zero to int32 extremes) and the decode-with-conversion path against
+    from_f64 of the float64 decode (every PCM format, N = 2048 stereo fused kernel included)."""
+    be = GpuBackend()
+    rng = np.random.default_rng(int(os.environ.get("FRAD_FUZZ_SEED", "20261004")) + 2)
+    rounds = max(10, int(os.environ.get("FRAD_FUZZ_N", "220")) // 8)
+    from frad_python_amd.fourier import profiles
+    fmts = ["u8", "u16le", "u16be", "s8", "s16le", "s16be", "s32le", "s32be", "s64le", "f16le", "f32le", "f32be", "f64be"]
+    for i in range(rounds):
+        N = int(rng.choice(profiles.compact.SAMPLES[:20])); C = int(rng.choice([1, 2, 2, 3, 6])); F = int(rng.choice([1, 3, 9]))
+        spread = float(rng.choice([0.0, 0.7, 5.0, 300.0, 2e5]))
+        q = np.rint(rng.laplace(0, spread, (F, N, C)) if spread else np.zeros((F, N, C))).clip(-2 ** 31 + 1, 2 ** 31 - 1).astype(np.int32)
+        if rng.integers(0, 6) == 0:
+            q[0, int(rng.integers(0, N)), 0] = int(rng.choice([2 ** 31 - 1, -2 ** 31 + 1, 2 ** 30, -2 ** 30 - 1]))
+        tq = rng.integers(0, 60, (F, 27, C)).astype(np.int32)
+        bodies = be.golomb_encode(q, tq)
+        for f in range(F):
+            tg, fg = fo.golomb_encode(tq[f].reshape(-1)), fo.golomb_encode(q[f].reshape(-1))
+            assert bodies[f] == len(tg).to_bytes(4, "big") + tg + fg, ("golomb encode", N, C, F, spread, f)
+        dq, dt, st = be.golomb_decode(bodies, N, C)
+        assert np.array_equal(dq, q) and np.array_equal(dt, tq) and not st.any(), ("golomb decode", N, C, F, spread)
+        # decode with the output conversion
+        Np = int(rng.choice([2048, 2048, 1024, 896, 4096, 300])); Cp = int(rng.choice([1, 2, 2, 4])); Fp = int(rng.choice([1, 4]))
+        bits = int(rng.choice([16, 32, 64, 24])); le = bool(rng.integers(0, 2)); fmt = str(rng.choice(fmts)); prof = int(rng.choice([0, 0, 4]))
+        x = rng.uniform(-1.2, 1.2, (Fp, Np * Cp))
+        pay = np.stack([np.frombuffer(fo.pack_floats(x[f], bits, le), np.uint8) for f in range(Fp)])
+        got = be.digital_pcm(prof, pay, Fp, Np, Cp, bits, le, fmt)
+        f64 = be.digital(prof, pay, Fp, Np, Cp, bits, le)
+        dt_ = fo.pcm_dtype(fmt)
+        if fmt.startswith(("u32", "u64")):
+            continue
+        with np.errstate(all="ignore"):
+            want = fo.from_f64(f64, dt_).astype(dt_)
+        assert got.tobytes() == want.tobytes(), ("digital_pcm", prof, Np, Cp, Fp, bits, le, fmt)
+    print("entropy / epilogue fuzz:", rounds, "rounds ok")
