@@ -254,3 +254,51 @@ def test_lossless_frame_length_comes_from_the_payload(kind):
     want = fo.decode_stream(bytes(stream))
     got, frames = _decode(kind, bytes(stream), 4096, 2)
     assert got.shape == want.shape == (3000, 2) and np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_streaming_api_under_random_chunking():
+    """Encoder / Decoder on the HIP bridge fed in random chunk sizes (the table-driven header scan, strided batched
+    decode, carry-over of half headers / half frames, tails and flushes): what comes out must not depend on the chunking
+    and must match the oracle's one-shot encode / decode."""
+    rng = np.random.default_rng(2026)
+    for it in range(12):
+        profile = int(rng.choice([0, 4, 1, 0]))
+        C = int(rng.choice([1, 2, 2, 3]))
+        fsize = int(rng.choice([256, 1024, 2048, 2048, 4096] if profile != 1 else [1024, 2048, 2048]))
+        n = int(rng.integers(1, 9) * fsize + rng.integers(0, fsize))
+        fmt = str(rng.choice(["s16le", "s16le", "f32le", "u8"])) if profile != 1 else "s16le"
+        bits = int(rng.choice([16, 32, 64])) if profile != 1 else 16
+        pcm = synth.to_pcm(synth.harmonic_mix(n, C, 48000, seed=it) * 0.7, fmt).tobytes()
+        p = dict(profile=profile, srate=48000, channels=C, bits=bits, frame_size=fsize, pcm_format=fmt,
+                 little_endian=bool(rng.integers(0, 2)), overlap_ratio=int(rng.choice([0, 8, 16])) if profile == 1 else 0)
+        ref = fo.encode_stream(pcm, **p)
+        want = fo.decode_stream(ref)
+        # encode in random chunks
+        enc = Encoder(profile, 48000, C, bits, fsize, fmt, bridge=_bridge("gpu"))
+        enc.set_little_endian(p["little_endian"]); enc.set_overlap_ratio(p["overlap_ratio"]); enc.set_loss_level(0.5)
+        out, pos, samples = b"", 0, 0
+        while pos < len(pcm):
+            step = int(rng.choice([1, 37, 4096, 65536, 1 << 20])) * (1 if rng.integers(0, 2) else 3)
+            r = enc.process(pcm[pos:pos + step]); out += r.buf; samples += r.samples; pos += step
+        r = enc.flush(); out += r.buf; samples += r.samples
+        assert samples == n, (it, p)
+        got_from_ours = fo.decode_stream(out)
+        assert got_from_ours.shape == want.shape, (it, p)
+        if profile == 4:
+            assert out == ref, (it, p)
+        elif profile == 0:
+            tol = {16: 2e-3, 32: 1e-6, 64: 1e-12}[bits]
+            assert np.max(np.abs(got_from_ours - want)) <= tol, (it, p)
+        else:
+            assert 10 * np.log10(1.0 / max(np.mean((got_from_ours - want) ** 2), 1e-300)) > 100, (it, p)
+        # decode the reference stream in random chunks
+        dec = Decoder(bridge=_bridge("gpu"))
+        pieces, pos, frames = [], 0, 0
+        while pos < len(ref):
+            step = int(rng.choice([1, 5, 33, 1000, 50000, 1 << 20]))
+            d = dec.process(ref[pos:pos + step]); pieces.append(d.pcm.reshape(-1, C)); frames += d.frames; pos += step
+        pieces.append(dec.flush().pcm.reshape(-1, C))
+        got = np.concatenate([x for x in pieces if x.size])
+        assert got.shape == want.shape, (it, p, got.shape, want.shape)
+        assert np.max(np.abs(got - want)) <= 1e-12 * max(1.0, np.max(np.abs(want))), (it, p)
