@@ -320,7 +320,7 @@ int get_blue(int N, int log2l, BlueTable& out) {
 }
 
 struct BlueCfg { bool ok = false; int log2l = 0, cg = 0, threads = 0, whole = 0, paired = 0; size_t lds = 0; };
-BlueCfg blue_cfg(int N, int C, int bits, bool fwd) {
+BlueCfg blue_cfg(int N, int C, int bits, bool fwd, bool allow_pairs = true) {
     BlueCfg c;
     if (N < 96 || N > 4096) return c;                        // tiny frames: the direct product is cheaper
     if (const char* e = tune("FRAD_TUNE_NO_BLUE")) { if (atoi(e) != 0) return c; }   // A/B knob, not part of the ABI
@@ -338,7 +338,9 @@ BlueCfg blue_cfg(int N, int C, int bits, bool fwd) {
         if (fwd && bits == 12 && (C & 1)) return c;          // packing: 12-bit pairs must not straddle groups (reads may)
     }
     static const bool no_pairs = [] { const char* e = tune("FRAD_TUNE_BLUE_NO_PAIRS"); return e && e[0] == '1'; }();
-    c.paired = (c.whole && (C & 1) == 0 && !no_pairs) ? 1 : 0;   // two channels per complex transform
+    // two channels per complex transform -- not for float PCM on the way in: a NaN / Inf sample of one channel would
+    // poison its partner through the shared convolution (integers cannot carry one; decode scrubs them first)
+    c.paired = (c.whole && (C & 1) == 0 && !no_pairs && allow_pairs) ? 1 : 0;
     const long long need = c.paired ? C / 2 : C;
     if (cg > need) cg = need;
     if (cg * team > 1024) cg = 1024 / team;
@@ -364,8 +366,8 @@ void go_inv(const BlueCfg& c, dim3 grid, hipStream_t s, const unsigned char* pay
     hipLaunchKernelGGL((k_p0_inv_blue<LOG2L>), grid, dim3(c.threads), c.lds, s, pay, out, tw, t.wconj, t.bhat, t.pw, g, ai);
 }
 
-int tables_for(int N, int C, int bits, bool fwd, BlueCfg& c, BlueTable& t, const cx<double>** tw) {
-    c = blue_cfg(N, C, bits, fwd);
+int tables_for(int N, int C, int bits, bool fwd, BlueCfg& c, BlueTable& t, const cx<double>** tw, bool allow_pairs = true) {
+    c = blue_cfg(N, C, bits, fwd, allow_pairs);
     if (!c.ok) return 0;
     Tables ft; int rc = get_tables(c.log2l, false, ft);
     if (rc != FRAD_OK) return rc;
@@ -395,7 +397,7 @@ void blue_clear() {
 int launch_p0_fwd_blue(int lg, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* absmax, Geom g, int aligned_out) {
     if (g.n_frames > 0x7fffffffLL) return 0;
     BlueCfg c; BlueTable t; const cx<double>* tw = nullptr;
-    const int r = tables_for(g.N, g.C, g.bits, true, c, t, &tw);
+    const int r = tables_for(g.N, g.C, g.bits, true, c, t, &tw, (g.dtype >> 3) != 2);
     if (r <= 0) return r;
     if (absmax) BCHK(hipMemsetAsync(absmax, 0, sizeof(double) * (size_t)g.n_frames, s));       // atomicMax target
     g.cg = c.cg; g.fpb = 1; g.in_mode = c.whole; g.cc_fast = c.paired;

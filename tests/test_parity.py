@@ -356,3 +356,26 @@ def test_p0_decode_scrubs_both_infinities(be, bits):
     got = be.digital(0, raw, F, N, C, bits, False)
     assert np.all(np.isfinite(got))
     assert np.max(np.abs(got - want)) <= 16 * EPS64 * np.log2(N) * max(1.0, np.max(np.abs(want)))
+
+
+@pytest.mark.parametrize("N", [2048, 1024, 896])
+def test_p0_nan_and_inf_samples_in_float64_pcm(be, N):
+    """float64 PCM may carry NaN / Inf (to_f64 passes floats through): the reference's DCT then turns that channel's whole
+    frame into NaN, np.max(np.abs(.)) is NaN and the overflow test does not fire (profile0.py:21-26).  Wave (2048), unit
+    (1024) and Bluestein (896) kernels."""
+    C, F = 2, 2
+    rng = np.random.default_rng(N)
+    x = rng.uniform(-1, 1, (F * N, C))
+    x[5, 0] = np.nan                                           # frame 0, channel 0
+    x[N + 7, 1] = np.inf                                       # frame 1, channel 1
+    raw = synth.to_pcm(x, "f64le")
+    pay, am = be.analogue(0, raw, "f64le", F, N, C, 32, False)
+    ref = oracle_frames(fo, 0, raw, "f64le", F, N, C, 32, False)
+    for f in range(F):
+        gv, wv = payload_values(fo, pay[f], 32, False), payload_values(fo, ref[f][0], 32, False)
+        # (which of the poisoned bins are NaN and which +-Inf depends on the operation order -- pocketfft keeps +Inf in
+        # bin 0 of a channel with one +Inf sample, a butterfly network meets inf - inf there; both are "not finite")
+        assert np.array_equal(np.isfinite(gv), np.isfinite(wv)), (N, f)
+        ok = np.isfinite(wv)
+        assert np.max(np.abs(gv[ok] - wv[ok])) <= (2.0 ** -23 + 8 * EPS64 * np.log2(N)) * np.max(np.abs(wv[ok])), (N, f)
+        assert np.isnan(am[f]) == np.isnan(ref[f][2]), (N, f, am[f], ref[f][2])
