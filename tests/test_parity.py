@@ -338,12 +338,13 @@ def test_p0_two_channel_groups_whole_rows(be, fmt, bits, le):
         assert np.max(np.abs(dec[f] - ref[f][1])) <= 16 * EPS64 * np.log2(N) * max(1.0, np.max(np.abs(ref[f][1])))
 
 
+@pytest.mark.parametrize("N", [2048, 1024, 256, 896, 6000])
 @pytest.mark.parametrize("bits", [16, 32])
-def test_p0_decode_scrubs_both_infinities(be, bits):
+def test_p0_decode_scrubs_both_infinities(be, bits, N):
     """profile0.digital zeroes NaN, +Inf AND -Inf before the inverse transform (profile0.py:66).  Found by a long fuzz run:
     the N = 2048 wave decode kernel's float-class mask lacked -Inf (unscaled big-endian integers overflow a 16-bit
     payload in both directions)."""
-    N, C, F = 2048, 2, 2
+    C, F = 2, 2                                              # wave, unit, one-shot, Bluestein (pairs) and workspace kernels
     rng = np.random.default_rng(bits)
     x = rng.uniform(-1, 1, (F, N * C))
     store = np.float16 if bits == 16 else np.float32
