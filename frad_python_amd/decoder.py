@@ -117,7 +117,8 @@ class Decoder:
                         return zlib.decompress(frad, wbits=-15)
                     except Exception:
                         return None                                  # profile1.py:59-60 -> a frame of zeros
-                bodies = [inflate(frad) for frad in payloads]      # (inflate is ~20 us a frame: a thread pool costs more than it saves)
+                from .encoder import _map_zlib
+                bodies = _map_zlib(inflate, payloads)              # runs of frames per pool task
                 bad = [i for i, b in enumerate(bodies) if b is None]
                 bodies = [b if b is not None else b"" for b in bodies]
                 pcm = on_device(bodies, fsize, channels, bits, srate)

@@ -25,15 +25,23 @@ _POOL = None
 
 def _map_zlib(fn, items: list) -> list:
     """deflate / inflate of a batch's frames on a small thread pool: zlib releases the GIL, the frames are independent and
-    the results are the bytes the serial loop would give (profile1.py:50, :59)"""
+    the results are the bytes the serial loop would give (profile1.py:50, :59).  Work is handed out in runs of frames so
+    that the pool's per-task overhead (tens of microseconds) does not exceed a frame's own cost."""
     global _POOL
-    if len(items) < 8:
+    n = len(items)
+    if n < 32:
         return [fn(b) for b in items]
     if _POOL is None:
         import os
         from concurrent.futures import ThreadPoolExecutor
         _POOL = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4))
-    return list(_POOL.map(fn, items, chunksize=max(1, len(items) // 64)))
+    workers = _POOL._max_workers
+    run = max(8, -(-n // (4 * workers)))
+    chunks = [items[i:i + run] for i in range(0, n, run)]
+    out = []
+    for part in _POOL.map(lambda ch: [fn(b) for b in ch], chunks):
+        out.extend(part)
+    return out
 
 
 class EncodeResult:
