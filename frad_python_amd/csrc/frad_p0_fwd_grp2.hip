@@ -19,21 +19,25 @@ __device__ __forceinline__ void put_code(uint32_t (&w)[NW], int j, u64 code, boo
     else { const u64 c = le ? code : bswap64(code); w[2 * j] = (uint32_t)c; w[2 * j + 1] = (uint32_t)(c >> 32); }
 }
 
-template <int LOG2M, int CG, int LG, int BITS>
-__global__ void __launch_bounds__(CG * Plan<LOG2M>::TEAM)
+template <int LOG2M, int CG, int LG, int BITS, int NH = 1>
+__global__ void __launch_bounds__(CG * Plan<LOG2M>::TEAM, NH)   // NH = 2: 256 threads, two blocks per CU -> 2 waves per SIMD
 k_p0_fwd_grp2(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload, double* absmax,
               const cx<double>* __restrict__ tw, const cx<double>* __restrict__ post, Geom g) {
     constexpr int M = 1 << LOG2M, N = 2 * M, TEAM = Plan<LOG2M>::TEAM, SH = Plan<LOG2M>::SH, SLOTS = padded_slots(M);
-    constexpr int T = CG * TEAM, RPT = N / T, C = 2 * CG, NBV = BITS / 8;
+    constexpr int T = CG * TEAM, RPT = N / T, C = 2 * CG * NH, NBV = BITS / 8;
     constexpr int IW = (CG << LG) / 4;                        // words of half a PCM row
-    constexpr int OW = CG * NBV / 4, ROW_OUT = C * NBV;       // words of half a payload row; bytes of a whole one
-    static_assert(N % T == 0 && ((CG << LG) % 4) == 0 && IW >= 1 && (CG * NBV) % 4 == 0 && ROW_OUT % 16 == 0, "whole words per half row");
+    constexpr int OW = CG * NBV / 4, ROW_OUT = C * NBV;       // words of a group's share of a payload row; bytes of a whole row
+    static_assert(N % T == 0 && ((CG << LG) % 4) == 0 && IW >= 1 && (CG * NBV) % 4 == 0 && (2 * OW) % 4 == 0, "whole 16-byte pieces per block and row");
     FRAD_DYN_SMEM(smem);
-    const long long f = blockIdx.x;
+    // NH = 2: a frame's rows are shared by two blocks (2 x CG channels each); blocks b and b + 8 run on the same XCD
+    // (round-robin dispatch) and read / write their halves of every row through one L2 (frad_p0_inv_grp2.hip)
+    long long f = blockIdx.x;
+    int part = 0;
+    if constexpr (NH == 2) { const long long r = f >> 3; part = (int)(r & 1); f = (r >> 1) * 8 + (f & 7); if (f >= g.n_frames) return; }
     const int cf = threadIdx.x / TEAM, t = threadIdx.x - cf * TEAM;
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem) + (long long)cf * SLOTS;
     const bool le = g.le != 0;
-    const unsigned char* src = pcm + ((f * g.frame_stride * C) << LG);
+    const unsigned char* src = pcm + ((f * g.frame_stride * C) << LG) + part * (2 * IW * 4);
     constexpr int ROW_IN = C << LG;
     uint32_t hold[RPT][IW];
     u64 mx = 0;
@@ -45,9 +49,10 @@ k_p0_fwd_grp2(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int n = threadIdx.x + i * T;
-            uint32_t w[IW];
-            load_words<IW>(src + (long long)n * ROW_IN, w);
-            load_words<IW>(src + (long long)n * ROW_IN + IW * 4, hold[i]);
+            uint32_t w[IW], both[2 * IW];                     // this block's share of the row in one access
+            load_words<2 * IW>(src + (long long)n * ROW_IN, both);
+#pragma unroll
+            for (int q = 0; q < IW; ++q) { w[q] = both[q]; hold[i][q] = both[IW + q]; }
             const int m = makhoul(n, N);
 #pragma unroll
             for (int j = 0; j < CG; ++j) xslot<double, SH>(smem, j, SLOTS, m) = elem(w, j);
@@ -85,7 +90,7 @@ k_p0_fwd_grp2(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         dct_post<double, LOG2M>(buf, tt, post);
         __syncthreads();
         // ---- whole payload rows out
-        unsigned char* dst = payload + f * g.payload_stride;
+        unsigned char* dst = payload + f * g.payload_stride + part * (2 * OW * 4);
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int k = threadIdx.x + i * T;
@@ -113,23 +118,23 @@ k_p0_fwd_grp2(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
 }
 
 namespace {
-template <int LOG2M, int CG, int LG>
+template <int LOG2M, int CG, int LG, int NH = 1>
 int go_bits(int bits, size_t lds, dim3 grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* am,
             const cx<double>* tw, const cx<double>* post, const Geom& g) {
     constexpr int T = CG * Plan<LOG2M>::TEAM;
-#define GO(B) do { allow_lds(k_p0_fwd_grp2<LOG2M, CG, LG, B>, lds); \
-        hipLaunchKernelGGL((k_p0_fwd_grp2<LOG2M, CG, LG, B>), grid, dim3(T), lds, s, pcm, pay, am, tw, post, g); } while (0)
+#define GO(B) do { allow_lds(k_p0_fwd_grp2<LOG2M, CG, LG, B, NH>, lds); \
+        hipLaunchKernelGGL((k_p0_fwd_grp2<LOG2M, CG, LG, B, NH>), grid, dim3(T), lds, s, pcm, pay, am, tw, post, g); } while (0)
     if (bits == 32) { GO(32); return 1; }
     if (bits == 64) { GO(64); return 1; }
-    if constexpr ((2 * CG * 2) % 16 == 0) { if (bits == 16) { GO(16); return 1; } }
+    if constexpr ((2 * CG * 2) % 16 == 0) { if (bits == 16) { GO(16); return 1; } }   // (store_words moves 16-byte pieces)
 #undef GO
     return 0;
 }
-template <int LOG2M, int CG>
+template <int LOG2M, int CG, int NH = 1>
 int go_lg(int lg, int bits, size_t lds, dim3 grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* am,
           const cx<double>* tw, const cx<double>* post, const Geom& g) {
-    if (lg == 1) { if constexpr ((CG << 1) % 4 == 0) return go_bits<LOG2M, CG, 1>(bits, lds, grid, s, pcm, pay, am, tw, post, g); else return 0; }
-    if (lg == 2) return go_bits<LOG2M, CG, 2>(bits, lds, grid, s, pcm, pay, am, tw, post, g);
+    if (lg == 1) { if constexpr ((CG << 1) % 4 == 0) return go_bits<LOG2M, CG, 1, NH>(bits, lds, grid, s, pcm, pay, am, tw, post, g); else return 0; }
+    if (lg == 2) return go_bits<LOG2M, CG, 2, NH>(bits, lds, grid, s, pcm, pay, am, tw, post, g);
     return 0;                                                 // 8-byte PCM: 64 registers of parked input per lane -- the generic kernel
 }
 }  // namespace
@@ -144,6 +149,15 @@ int launch_p0_fwd_grp2(int lg, const FastCfg& c, hipStream_t s, const unsigned c
     const cx<double>* tw = static_cast<const cx<double>*>(tb.tw);
     const cx<double>* post = static_cast<const cx<double>*>(tb.post);
     dim3 grid((unsigned)g.n_frames);
+    // two half-size blocks per frame, two resident per CU (see launch_p0_inv_grp2)
+    if (!tune("FRAD_TUNE_GRP2_WHOLE")) {
+        const long long nb = ((g.n_frames + 7) / 8) * 16;
+        if (nb <= 0x7fffffffLL) {
+            const dim3 grid2((unsigned)nb);
+            if (c.log2m == 10 && c.cg == 8 && go_lg<10, 4, 2>(lg, g.bits, c.lds / 2, grid2, s, pcm, pay, am, tw, post, g)) return 1;
+            if (c.log2m == 11 && c.cg == 4 && go_lg<11, 2, 2>(lg, g.bits, c.lds / 2, grid2, s, pcm, pay, am, tw, post, g)) return 1;
+        }
+    }
     if (c.log2m == 10 && c.cg == 8) return go_lg<10, 8>(lg, g.bits, c.lds, grid, s, pcm, pay, am, tw, post, g);
     if (c.log2m == 11 && c.cg == 4) return go_lg<11, 4>(lg, g.bits, c.lds, grid, s, pcm, pay, am, tw, post, g);
     if (c.log2m == 12 && c.cg == 2) return go_lg<12, 2>(lg, g.bits, c.lds, grid, s, pcm, pay, am, tw, post, g);

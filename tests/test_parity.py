@@ -320,10 +320,11 @@ def test_golden_g1_vectors(be):
 
 
 @pytest.mark.parametrize("fmt,bits,le", [("s16le", 16, False), ("s16le", 32, True), ("s32le", 64, False), ("u16le", 32, False)])
-def test_p0_two_channel_groups_whole_rows(be, fmt, bits, le):
+def test_p0_two_channel_groups_whole_rows(be, fmt, bits, le, geom=None):
     """Frames whose float64 channels need exactly two passes through a CU's LDS (C = 2 x channel group): the whole-row
     kernels k_p0_fwd_grp2 / k_p0_inv_grp2 (8 channels at N = 4096 on the GPU; 16 channels at N = 2048 fits the emulator)."""
-    N, C, F = (2048, 16, 2) if be.name == "emu" else (4096, 8, 5)
+    # frame counts above the (emulated: 3) CU count: the decode kernel is persistent and fetches its next frame early
+    N, C, F = geom or ((2048, 16, 8) if be.name == "emu" else (4096, 8, 530))
     rng = np.random.default_rng(N + bits)
     raw = synth.to_pcm(rng.uniform(-1, 1, (F * N, C)), fmt)
     pay, am = be.analogue(0, raw, fmt, F, N, C, bits, le)
@@ -336,6 +337,13 @@ def test_p0_two_channel_groups_whole_rows(be, fmt, bits, le):
     dec = be.digital(0, np.stack([r[0] for r in ref]), F, N, C, bits, le)
     for f in range(F):
         assert np.max(np.abs(dec[f] - ref[f][1])) <= 16 * EPS64 * np.log2(N) * max(1.0, np.max(np.abs(ref[f][1])))
+
+
+@pytest.mark.parametrize("fmt,bits,le", [("s16le", 32, False), ("s32le", 64, True)])
+def test_p0_cfg4_rows_shared_by_two_blocks(be, fmt, bits, le):
+    """cfg 4's geometry (N = 4096, 8 channels, 32 / 64 bit): the decode splits every frame's rows between two blocks
+    (k_p0_inv_grp2<.., NH = 2>); a frame count that is not a multiple of 8 exercises the XCD pairing's guard."""
+    test_p0_two_channel_groups_whole_rows(be, fmt, bits, le, geom=(4096, 8, 11 if be.name == "emu" else 531))
 
 
 @pytest.mark.parametrize("N", [2048, 1024, 256, 896, 6000])
