@@ -62,6 +62,9 @@ def test_random_geometries_against_oracle():
         F = int(rng.choice([1, 2, 3, 7, 33]))
         if kind == 3:
             F, C = int(rng.choice([1, 2])), int(rng.choice([1, 2, 3]))
+        if i % 10 == 5:                                      # frames of exactly two channel groups (the two-pass kernels: a frame's
+            N, C = [(2048, 16), (4096, 8), (8192, 4), (16384, 2)][int(rng.integers(0, 4))]   # rows split between two blocks,
+            F = int(rng.choice([1, 3, 9, 17]))               # partners 8 blocks apart -- frame counts around that guard)
         while N * C * F > 600000:
             F = max(1, F // 2)
             if F == 1 and N * C > 600000:
