@@ -141,7 +141,8 @@ bool p1_fast_fits(FastCfg& c, int N, int C) {
     return (size_t)c.fpb * C * M * 16 + p1_scratch_bytes(c.fpb * C, N) <= 160 * 1024;
 }
 
-// |q|^(1/0.75) for q = 0 .. 255 (p1tools.py:44 dequant), long double -> correctly rounded double; one table per device
+// |q|^(1/0.75) for q = 0 .. 255 (p1tools.py:44 dequant) and the band thresholds' (e/2)^quant(t), long double -> correctly
+// rounded double; one table per device
 std::map<int, double*> g_deq;
 const double* deq_table() {
     int dev = 0;
@@ -149,8 +150,10 @@ const double* deq_table() {
     std::lock_guard<std::mutex> lk(g_band_mu);
     auto it = g_deq.find(dev);
     if (it != g_deq.end()) return it->second;
-    double host[256];
+    double host[512];
     for (int a = 0; a < 256; ++a) host[a] = (double)powl((long double)a, (long double)(1.0 / 0.75));
+    // (e/2)^quant(t), t = 0 .. 255 -- the dequantised band thresholds of profile1.py:63; quant(t) = t^0.75 as in p1w_quant
+    for (int t = 0; t < 256; ++t) { const double r = sqrt((double)t), qt = r * sqrt(r); host[256 + t] = (double)powl((long double)(2.718281828459045 / 2), (long double)qt); }
     double* d = nullptr;
     if (hipMalloc(&d, sizeof host) != hipSuccess) return nullptr;
     if (hipMemcpy(d, host, sizeof host, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }

@@ -206,13 +206,15 @@ struct P1Wave {
     double scale, loss;          // 2^(bits-1); max(|loss_level|, 0.125)
     int nb_used;                 // bands before the first empty one
     const unsigned char* band_of;// device table [N]: band of bin k (0..25), 255 = beyond the last band start
-    const double* deq;           // device table [256]: a^(1/0.75) for a = 0 .. 255 (p1tools.py:44), correctly rounded
+    const double* deq;           // device table [512]: a^(1/0.75) for a = 0 .. 255 (p1tools.py:44), then (e/2)^(t^0.75) for
+                                 // t = 0 .. 255 (profile1.py:63), both correctly rounded
     const int32_t* tq_in;        // K8: [n_frames, 27, C]
     int32_t* tq_out;             // K7: [n_frames, 27, C]
 };
 struct P1None {};
-constexpr int kP1BlockBytes = 2048 + 32 * 4 + 32 * 8 + 256 * 8;   // band_of[2048] | edge[32] | floor[32] | deq[256], after the work counter
+constexpr int kP1BlockBytes = 2048 + 32 * 4 + 32 * 8 + 512 * 8;   // band_of[2048] | edge[32] | floor[32] | deq[256] | thr[256], after the work counter
 constexpr int kWaveLdsBytesP1 = kWaveLdsBytes + 16 + kP1BlockBytes;
+static_assert(kWaveLdsBytesP1 <= 160 * 1024, "a CU's LDS");
 struct P1Lds2 { const unsigned char* band; const int* edge; const double* floor_; const double* deq; };
 __device__ __forceinline__ P1Lds2 p1w_lds(unsigned char* smem) {
     unsigned char* b = smem + kWaveLdsBytes + 16;
@@ -223,7 +225,7 @@ __device__ __forceinline__ void p1w_tables_to_lds(unsigned char* smem, const P1W
     for (int i = threadIdx.x; i < 512; i += blockDim.x) reinterpret_cast<uint32_t*>(b)[i] = reinterpret_cast<const uint32_t*>(pw.band_of)[i];
     if (threadIdx.x < 28) reinterpret_cast<int*>(b + 2048)[threadIdx.x] = pw.edge[threadIdx.x];
     if (threadIdx.x < 27) reinterpret_cast<double*>(b + 2048 + 128)[threadIdx.x] = pw.floor_[threadIdx.x];
-    if (threadIdx.x < 256 && pw.deq != nullptr) reinterpret_cast<double*>(b + 2048 + 128 + 256)[threadIdx.x] = pw.deq[threadIdx.x];
+    if (pw.deq != nullptr) for (int i = threadIdx.x; i < 512; i += blockDim.x) reinterpret_cast<double*>(b + 2048 + 128 + 256)[i] = pw.deq[i];
 }
 // per-wave scratch at the start of the wave's buffer: thr[2][32] | stp[2][32] | acc[2][32] doubles (index h * 32 + band)
 __device__ __forceinline__ double p1w_spread(const P1Lds2& t, const double* thr, const double* stp, int h, int k) {
@@ -232,7 +234,10 @@ __device__ __forceinline__ double p1w_spread(const P1Lds2& t, const double* thr,
     const int a = t.edge[j];
     const double i = (double)(k - a), st = stp[h * 32 + j], t0 = thr[h * 32 + j];
     double y = i * st;
-    if (st == 0.0) y = (i / (double)(t.edge[j + 1] - a)) * (thr[h * 32 + j + 1] - t0);      // numpy's denormal-safe branch
+    if (st == 0.0) {                                          // equal neighbours (common: y stays +0) or a step that underflowed:
+        const double d = thr[h * 32 + j + 1] - t0;            // numpy's denormal-safe branch (p1tools.py:35-41), the division
+        if (d != 0.0) y = (i / (double)(t.edge[j + 1] - a)) * d;     // only when it can matter
+    }
     return y + t0;
 }
 __device__ __forceinline__ double p1w_quant(double x) {        // sign(x) |x|^0.75 (p1tools.py:43)
@@ -1068,6 +1073,8 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
         }
     };
     [[maybe_unused]] const P1Lds2 p1t = p1w_lds(smem);
+    [[maybe_unused]] double inv_scale = 1.0;
+    if constexpr (MODE == 1) inv_scale = 1.0 / pw.scale;
     [[maybe_unused]] double* const thr = reinterpret_cast<double*>(wbuf);      // MODE 1: this wave's thresholds and ramp steps,
     [[maybe_unused]] double* const stp = thr + 64;                             //         valid from the unit's start to its pair step
     auto value = [&](code_t c, [[maybe_unused]] int kbin) -> T {   // stored code -> float64, NaN / Inf -> 0 (profile0.py:62-66)
@@ -1078,8 +1085,16 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
             const int hh = (threadIdx.x >> 5) & 1;
             const int32_t aq = qv < 0 ? -qv : qv;
             // |q|^(1/0.75): small magnitudes (nearly all of them) from the LDS table, the rest through cbrt
+#if defined(FRAD_X_K8) && (FRAD_X_K8 & 2)
+            const double dq = (double)qv; (void)aq;
+#else
             const double dq = (uint32_t)aq < 256u ? (qv < 0 ? -p1t.deq[aq] : p1t.deq[aq]) : p1w_dequant((double)qv);
-            return (dq / pw.scale) * p1w_spread(p1t, thr, stp, hh, kbin);
+#endif
+#if defined(FRAD_X_K8) && (FRAD_X_K8 & 1)
+            (void)hh; return (dq * inv_scale) * thr[kbin & 31];
+#else
+            return (dq * inv_scale) * p1w_spread(p1t, thr, stp, hh, kbin);
+#endif   // scale = 2^(bits-1): the product is the quotient, exactly
         } else
         if constexpr (BITS == 32) {
             float f = u2f(wave_perm(c, psel));
@@ -1106,6 +1121,16 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
 
     long long u = ub + wv;
     if constexpr (PF) { if (u < ue) load_words(u, -1); }
+    // MODE 1: lane (h, l < 27)'s quantised band threshold of a unit, fetched one unit ahead like the payload words
+    [[maybe_unused]] int32_t tq_pf = 0;
+    [[maybe_unused]] auto tq_fetch = [&](long long un) -> int32_t {
+        if constexpr (MODE == 1) {
+            const int hh = (threadIdx.x >> 5) & 1, ll = threadIdx.x & 31;
+            const long long ft = CC == 2 ? un : frame_of(un, hh);
+            return ll < 27 ? pw.tq_in[(ft * 27 + ll) * CC + (CC == 2 ? hh : 0)] : 0;
+        } else { (void)un; return 0; }
+    };
+    if constexpr (MODE == 1) { if (u < ue) tq_pf = tq_fetch(u); }
     __syncthreads();                                          // tables and counter are in LDS
     for (int i = (wv * 8 + (int)(blockIdx.x & 7)) * g.cg; i > 0; --i) FRAD_WAVE_SLEEP(1);      // start stagger (g.cg x 64 cycles per step; 0 = off)
     while (u < ue) {
@@ -1114,12 +1139,16 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
         const bool lane0 = (l == 0);
         const long long next = ub + wave_next_unit(ctr);
         if constexpr (!PF) load_words(u, -1);
+#if defined(FRAD_X_K8) && (FRAD_X_K8 & 4)
+        if constexpr (false) {
+#else
         if constexpr (MODE == 1) {
+#endif
             // thresholds of this unit's frame(s): thr[b] = (e/2)^quant(tq[b]) (profile1.py:63), ramp steps (p1tools.py:35-41)
-            const long long ft = CC == 2 ? u : frame_of(u, h);
             if (l < 27) {
-                const double t = (double)pw.tq_in[(ft * 27 + l) * CC + (CC == 2 ? h : 0)];
-                thr[h * 32 + l] = pow(2.718281828459045 / 2, p1w_quant(t));
+                const int32_t ti = tq_pf;
+                // small codes (all that a sane stream holds) from the LDS table; pow only if some lane's code is not one
+                thr[h * 32 + l] = (uint32_t)ti < 256u ? p1t.deq[256 + ti] : pow(2.718281828459045 / 2, p1w_quant((double)ti));
             }
             team_sync<64>();
             if (l < 27) {
@@ -1281,6 +1310,7 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
                 // a quarter of the next unit's payload words per group, into the registers this group's samples have just
                 // freed (the first quarter before any store of this unit: waiting for it never waits for a store)
                 if constexpr (PF) { load_words(next < ue ? next : u, gq); }
+                if constexpr (MODE == 1) { if (gq == 0) tq_pf = tq_fetch(next < ue ? next : u); }
                 team_sync<64>();
                 FRAD_FENCE();
                 if constexpr (OUT >= 0) {
