@@ -322,6 +322,13 @@ __device__ __forceinline__ void half_wave_sum_f64(double v, double& lo, double& 
     hi = u2d(read_lane_u64(d2u(v), 32)) + u2d(read_lane_u64(d2u(v), 48));
 #endif
 }
+__device__ __forceinline__ int wave_read_lane(int v, int src) {      // v of lane `src` (wave-uniform index), as a scalar
+#ifdef FRAD_HOST_EMULATION
+    return (int)__shfl((unsigned long long)(unsigned)v, src, 64);
+#else
+    return __builtin_amdgcn_readlane(v, src);
+#endif
+}
 __device__ __forceinline__ int wave_uniform_int(int v) {
 #ifdef FRAD_HOST_EMULATION
     return (int)__shfl((unsigned long long)(unsigned)v, 0, 64);
@@ -374,9 +381,15 @@ __device__ __forceinline__ void wave_p1_quantise(const cx<T> (&E)[16], const cx<
     // The 32 bins a half-wave holds per (slot, class) are consecutive, so the bands they touch are the same for every
     // lane and both channels: band range and edges are wave-uniform (scalar registers), membership is two compares, and
     // nothing is gathered per lane.
+    // The lookups themselves are lane reads of three registers filled once per unit -- lane 4 s + cls holds the segment's
+    // first and last band, lane b edge[b], lanes 0 / 1 the bands of bins 512 / 1536: a wave-uniform LDS read in the middle
+    // of every segment costs a full LDS round trip plus a readfirstlane each, ~400 times per frame.
+    const int vseg = (int)p1t.band[wave_seg_lo(lane >> 2, lane & 3)] | ((int)p1t.band[wave_seg_hi(lane >> 2, lane & 3)] << 8);
+    const int vedge = p1t.edge[l];                            // (edge[28 .. 31]: padding, never selected)
+    const int vmid = (int)p1t.band[512 + 1024 * (lane & 1)];
     auto seg_bands = [&](int s, int cls, int& blo, int& bhi) {
-        blo = wave_uniform_int((int)p1t.band[wave_seg_lo(s, cls)]);
-        bhi = wave_uniform_int((int)p1t.band[wave_seg_hi(s, cls)]);
+        const int v = wave_read_lane(vseg, 4 * s + cls);
+        blo = v & 255; bhi = v >> 8;
         if (bhi > 25) bhi = 25;                               // 255: beyond the last band start -- no band there
     };
     // ---- pass A: band energies sum((X * scale)^2) (p1tools.py:21-29); lane b of each half accumulates band b ----------
@@ -401,11 +414,15 @@ __device__ __forceinline__ void wave_p1_quantise(const cx<T> (&E)[16], const cx<
 #ifdef FRAD_X_P1_NOSUM
             accreg += v2; (void)blo; (void)bhi; (void)kb;
 #else
-            for (int b = blo; b <= bhi; ++b) {
-                const int ea = wave_uniform_int(p1t.edge[b]), eb = wave_uniform_int(p1t.edge[b + 1]);
-                double s0, s1;
-                half_wave_sum_f64((kb >= ea && kb < eb) ? v2 : 0.0, s0, s1);
-                accreg += (l == b) ? (h ? s1 : s0) : 0.0;
+            if (blo <= bhi) {
+                int ea = wave_read_lane(vedge, blo);
+                for (int b = blo; b <= bhi; ++b) {
+                    const int eb = wave_read_lane(vedge, b + 1);
+                    double s0, s1;
+                    half_wave_sum_f64((kb >= ea && kb < eb) ? v2 : 0.0, s0, s1);
+                    accreg += (l == b) ? (h ? s1 : s0) : 0.0;
+                    ea = eb;
+                }
             }
 #endif
         }
@@ -419,7 +436,7 @@ __device__ __forceinline__ void wave_p1_quantise(const cx<T> (&E)[16], const cx<
         xs[0] = S.x; xs[1] = -S.y;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int jb = wave_uniform_int((int)p1t.band[512 + 1024 * i]);
+            const int jb = wave_read_lane(vmid, i);
             const T v = xs[i] * pw.scale;
             double s0, s1;
             half_wave_sum_f64(lane0 ? v * v : 0.0, s0, s1);
@@ -457,7 +474,7 @@ __device__ __forceinline__ void wave_p1_quantise(const cx<T> (&E)[16], const cx<
     auto ramp = [&](int b, int ea, int eb, int kb) -> double {
         const double t0 = thr[h * 32 + b], st = stp[h * 32 + b], i = (double)(kb - ea);
         double y = i * st;
-        if (st == 0.0) y = (i / (double)(eb - ea)) * (thr[h * 32 + b + 1] - t0);
+        if (st == 0.0) { const double d = thr[h * 32 + b + 1] - t0; if (d != 0.0) y = (i / (double)(eb - ea)) * d; }   // see p1w_spread
         return y + t0;
     };
     ptab_load(0);
@@ -479,10 +496,14 @@ __device__ __forceinline__ void wave_p1_quantise(const cx<T> (&E)[16], const cx<
 #ifdef FRAD_X_P1_NORAMP
             div = thr[h * 32 + (blo & 15)] + (double)bhi;
 #else
-            for (int b = blo; b <= bhi; ++b) {
-                const int ea = wave_uniform_int(p1t.edge[b]), eb = wave_uniform_int(p1t.edge[b + 1]);
-                const double d = ramp(b, ea, eb, kb);
-                div = (kb >= ea && kb < eb) ? d : div;
+            if (blo <= bhi) {
+                int ea = wave_read_lane(vedge, blo);
+                for (int b = blo; b <= bhi; ++b) {
+                    const int eb = wave_read_lane(vedge, b + 1);
+                    const double d = ramp(b, ea, eb, kb);
+                    div = (kb >= ea && kb < eb) ? d : div;
+                    ea = eb;
+                }
             }
 #endif
 #ifdef FRAD_X_P1_NOQUANT
