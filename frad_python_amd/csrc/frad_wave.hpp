@@ -1015,7 +1015,6 @@ template <typename T> __device__ __forceinline__ cx<T> cmulc(cx<T> a, cx<T> w) {
 template <int CC, int BITS, int MODE, typename P1, int OUT = -1>
 __device__ __forceinline__ void
 wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ out, const cx<double>* __restrict__ blob, const Geom& g, const P1& pw) {
-    static_assert(OUT < 0 || CC == 2, "fused output conversion: stereo frames");
     using T = double;
     constexpr int M = 1024, N = 2048, NB = BITS / 8;
     static_assert(MODE == 0 || BITS == 32, "profile 1: the integers have the layout of a 32-bit payload");
@@ -1334,6 +1333,42 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
                 if constexpr (MODE == 1) { if (gq == 0) tq_pf = tq_fetch(next < ue ? next : u); }
                 team_sync<64>();
                 FRAD_FENCE();
+                if constexpr (OUT >= 0 && CC == 1) {
+                    // narrowed output, mono: lane (h, t) takes samples 256 hf + 8 t .. + 7 of its frame's 512 in the group (four
+                    // staged 16-byte pairs; the slot swizzle permutes pairs inside a 16-slot run), converts them and stores
+                    // 8 x itemsize contiguous bytes
+                    constexpr int okind = OUT >> 3, olg = (OUT >> 1) & 3, osz = 1 << olg;
+                    unsigned char* dn = reinterpret_cast<unsigned char*>(out) + ((live ? f : 0) * (long long)N + 512 * gq) * osz;
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        v4u r4[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int G = 256 * hf + 8 * lq + 2 * i, jb = G >> 7, S = G & 127;
+                            r4[i] = *reinterpret_cast<const v4u*>(sb + jb * BLK + hq * 4096 + ((S ^ (((S >> 4) & 3) << 1)) * 8));
+                        }
+                        if (hf == 1) team_sync<64>();
+                        u64 b[8];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            b[2 * i] = from_f64_bits<okind, olg>(u2d((u64)r4[i][0] | ((u64)r4[i][1] << 32)), false);
+                            b[2 * i + 1] = from_f64_bits<okind, olg>(u2d((u64)r4[i][2] | ((u64)r4[i][3] << 32)), false);
+                        }
+                        unsigned char* dl = dn + (256 * hf + 8 * lq) * osz;
+                        if constexpr (olg == 1) {
+                            const v4u o4 = {(uint32_t)(b[0] | (b[1] << 16)), (uint32_t)(b[2] | (b[3] << 16)), (uint32_t)(b[4] | (b[5] << 16)), (uint32_t)(b[6] | (b[7] << 16))};
+                            if (live) stream_store(dl, o4);
+                        } else if constexpr (olg == 2) {
+                            const v4u o4 = {(uint32_t)b[0], (uint32_t)b[1], (uint32_t)b[2], (uint32_t)b[3]}, o5 = {(uint32_t)b[4], (uint32_t)b[5], (uint32_t)b[6], (uint32_t)b[7]};
+                            if (live) { stream_store(dl, o4); stream_store(dl + 16, o5); }
+                        } else {
+                            static_assert(olg == 1 || olg == 2, "fused output conversion: 2- and 4-byte formats");
+                        }
+                        FRAD_FENCE();
+                    }
+                    FRAD_FENCE();
+                    continue;
+                } else
                 if constexpr (OUT >= 0) {
                     // narrowed output: lane t of half hf takes sample-frames 256 hf + 4 t .. + 3 of the group (four staged rows),
                     // converts the eight values and stores 8 x itemsize contiguous bytes
@@ -1395,11 +1430,11 @@ __global__ void FRAD_WAVE_BOUNDS
 k_p0_inv_wave(const unsigned char* __restrict__ payload, double* __restrict__ out, const cx<double>* __restrict__ blob, Geom g) {
     wave_inv_body<CC, BITS, 0>(payload, out, blob, g, P1None{});
 }
-// profile 0 decode straight to a narrower PCM format (stereo): frad_p0_digital_pcm
-template <int BITS, int OUT>
+// profile 0 decode straight to a narrower PCM format (stereo frames, or pairs of mono frames): frad_p0_digital_pcm
+template <int BITS, int OUT, int CC = 2>
 __global__ void FRAD_WAVE_BOUNDS
 k_p0_inv_wave_pcm(const unsigned char* __restrict__ payload, void* __restrict__ out, const cx<double>* __restrict__ blob, Geom g) {
-    wave_inv_body<2, BITS, 0, P1None, OUT>(payload, static_cast<double*>(out), blob, g, P1None{});
+    wave_inv_body<CC, BITS, 0, P1None, OUT>(payload, static_cast<double*>(out), blob, g, P1None{});
 }
 // K8: q int32 [n_frames, 2048, C] (as `payload`, stride 2048 * C * 4 bytes) + pw.tq_in -> float64 PCM
 template <int CC>

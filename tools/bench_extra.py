@@ -50,6 +50,14 @@ for ofmt, osz in (("s16le", 2), ("f32le", 4)):
                     timeit(lambda: core.digital_batch(0, enc0.payload, F, N, C, 32, out=ob, out_format=ofmt)), S))
 o0 = torch.empty((F, N, C), dtype=torch.float64, device=dev)
 out.append(line("p0 decode b32->f64 (cfg-2 size, for comparison)", S * 12, timeit(lambda: core.digital_batch(0, enc0.payload, F, N, C, 32, out=o0)), S))
+# the same samples as 28 124 mono frames (two frames per wave)
+pcm_m = pcm.reshape(-1, 1)
+enc_m = core.analogue_batch(0, pcm_m, "s16le", 2 * F, N, 1, 32, check_overflow=False)
+ob = torch.empty(S * 2, dtype=torch.uint8, device=dev)
+out.append(line("p0 decode b32->s16le, mono (conversion fused)", S * 6, timeit(lambda: core.digital_batch(0, enc_m.payload, 2 * F, N, 1, 32, out=ob, out_format="s16le")), S))
+om = torch.empty((2 * F, N, 1), dtype=torch.float64, device=dev)
+out.append(line("p0 decode b32->f64, mono (for comparison)", S * 12, timeit(lambda: core.digital_batch(0, enc_m.payload, 2 * F, N, 1, 32, out=om)), S))
+del pcm_m, enc_m, om
 # cfg 4: 60 s of 192 kHz 8-channel f32, N = 4096, 32 bit
 F, N, C = 2812, 4096, 8
 pcm4 = (torch.rand((F * N, C), generator=g, device=dev) * 1.8 - 0.9).to(torch.float32)
