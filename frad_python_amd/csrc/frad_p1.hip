@@ -150,8 +150,10 @@ const double* deq_table() {
     std::lock_guard<std::mutex> lk(g_band_mu);
     auto it = g_deq.find(dev);
     if (it != g_deq.end()) return it->second;
-    double host[512];
+    double host[768];
     for (int a = 0; a < 256; ++a) host[a] = (double)powl((long double)a, (long double)(1.0 / 0.75));
+    // (e/2)^((n + 1/2)^0.75): where the band code round(dequant(log(t) / log(e/2))) of profile1.py:38-40 steps from n to n + 1
+    for (int n = 0; n < 256; ++n) host[512 + n] = (double)powl((long double)(2.718281828459045 / 2), powl((long double)n + 0.5L, 0.75L));
     // (e/2)^quant(t), t = 0 .. 255 -- the dequantised band thresholds of profile1.py:63; quant(t) = t^0.75 as in p1w_quant
     for (int t = 0; t < 256; ++t) { const double r = sqrt((double)t), qt = r * sqrt(r); host[256 + t] = (double)powl((long double)(2.718281828459045 / 2), (long double)qt); }
     double* d = nullptr;
@@ -230,6 +232,8 @@ int frad_p1_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
     if (!tb.f32) {
         P1Wave pw = wave_tables(tb, N);
         pw.tq_out = tq;
+        const double* dt = deq_table();
+        pw.tqh = dt ? dt + 512 : nullptr;
         if (launch_p1_fwd_wave(lg, s, in, q, g, pw, ai, p1_unit_neg)) { P1CHK(hipGetLastError()); return FRAD_OK; }
     }
     FastCfg c = fast_cfg(N, C, false);

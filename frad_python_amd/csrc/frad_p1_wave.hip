@@ -32,7 +32,16 @@ void go_p1_fwd_lg(int lg, const void* blob, int grid, hipStream_t s, const unsig
 int launch_p1_fwd_wave(int lg, hipStream_t s, const unsigned char* pcm, int32_t* q, const Geom& g, const P1Wave& pw, int ai, unit_root_fn unit) {
     if (wave_off() || p1_wave_off() || g.N != 2048 || (g.C != 1 && g.C != 2) || !ai || g.n_valid != g.N || lg < 1) return 0;
     if ((g.dtype >> 3) == 2 && lg <= 2) return 0;              // f16 / f32 PCM: the reference's mixed-precision path (one-shot kernels)
-    if (pw.edge[26] < g.N || (reinterpret_cast<uintptr_t>(q) & 3)) return 0;
+    if (pw.edge[26] < g.N || (reinterpret_cast<uintptr_t>(q) & 15) || pw.tqh == nullptr) return 0;
+    // the tail's band-energy pass (wave_p1_tail): a run of 32 consecutive bins touches at most three bands and a band spans at
+    // most kK7Slots runs -- true for every table rate up to 48 kHz at this frame length
+    for (int b = 0; b < 26 && pw.edge[b] < g.N; ++b) {
+        if (pw.edge[b + 1] <= pw.edge[b]) return 0;                       // (bands are non-empty up to the one that holds bin N - 1)
+        const int last = (pw.edge[b + 1] < g.N ? pw.edge[b + 1] : g.N) - 1;
+        if ((last >> 5) - (pw.edge[b] >> 5) + 1 > kK7Slots) return 0;
+    }
+    auto band_at = [&](int k) { int b = 0; while (b < 25 && pw.edge[b + 1] <= k) ++b; return b; };
+    for (int r = 0; r < g.N / 32; ++r) if (band_at(32 * r + 31) - band_at(32 * r) > 2) return 0;
     const void* blob = wave_blob_get(unit);
     if (blob == nullptr) return 0;
     Geom gg = g;

@@ -210,9 +210,12 @@ struct P1Wave {
                                  // t = 0 .. 255 (profile1.py:63), both correctly rounded
     const int32_t* tq_in;        // K8: [n_frames, 27, C]
     int32_t* tq_out;             // K7: [n_frames, 27, C]
+    const double* tqh;           // K7: device table [256]: (e/2)^((n + 1/2)^0.75), the thresholds at which the band code of
+                                 // profile1.py:38-40 steps from n to n + 1 (correctly rounded)
 };
 struct P1None {};
-constexpr int kP1BlockBytes = 2048 + 32 * 4 + 32 * 8 + 512 * 8;   // band_of[2048] | edge[32] | floor[32] | deq[256] | thr[256], after the work counter
+// after the work counter: band_of[2048] | edge[32] | floor[32] | K8: deq[256] | thr[256] doubles; K7: kme[2048] shorts | tqh[256] doubles
+constexpr int kP1BlockBytes = 2048 + 32 * 4 + 32 * 8 + 2048 * 2 + 256 * 8;
 constexpr int kWaveLdsBytesP1 = kWaveLdsBytes + 16 + kP1BlockBytes;
 static_assert(kWaveLdsBytesP1 <= 160 * 1024, "a CU's LDS");
 struct P1Lds2 { const unsigned char* band; const int* edge; const double* floor_; const double* deq; };
@@ -226,6 +229,7 @@ __device__ __forceinline__ void p1w_tables_to_lds(unsigned char* smem, const P1W
     if (threadIdx.x < 28) reinterpret_cast<int*>(b + 2048)[threadIdx.x] = pw.edge[threadIdx.x];
     if (threadIdx.x < 27) reinterpret_cast<double*>(b + 2048 + 128)[threadIdx.x] = pw.floor_[threadIdx.x];
     if (pw.deq != nullptr) for (int i = threadIdx.x; i < 512; i += blockDim.x) reinterpret_cast<double*>(b + 2048 + 128 + 256)[i] = pw.deq[i];
+    if (pw.tqh != nullptr) for (int i = threadIdx.x; i < 256; i += blockDim.x) reinterpret_cast<double*>(b + 2048 + 128 + 256 + 4096)[i] = pw.tqh[i];
 }
 // per-wave scratch at the start of the wave's buffer: thr[2][32] | stp[2][32] | acc[2][32] doubles (index h * 32 + band)
 __device__ __forceinline__ double p1w_spread(const P1Lds2& t, const double* thr, const double* stp, int h, int k) {
@@ -329,6 +333,15 @@ __device__ __forceinline__ int wave_read_lane(int v, int src) {      // v of lan
     return __builtin_amdgcn_readlane(v, src);
 #endif
 }
+__device__ __forceinline__ bool wave_any(bool b) {                     // true in some lane (all 64 lanes call it)
+#ifdef FRAD_HOST_EMULATION
+    unsigned long long v = b ? 1 : 0;
+    for (int off = 1; off < 64; off <<= 1) v |= __shfl_xor(v, off, 64);
+    return v != 0;
+#else
+    return __builtin_amdgcn_ballot_w64(b) != 0;
+#endif
+}
 __device__ __forceinline__ int wave_uniform_int(int v) {
 #ifdef FRAD_HOST_EMULATION
     return (int)__shfl((unsigned long long)(unsigned)v, 0, 64);
@@ -336,189 +349,387 @@ __device__ __forceinline__ int wave_uniform_int(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 #endif
 }
-// the 32 consecutive bins a half-wave holds for job slot s, class cls (0: k, 1: M - k, 2: M + k, 3: N - k): first, last
-__host__ __device__ constexpr int wave_seg_lo(int s, int cls) {
-    const int t = s < 8 ? s : 15 - s, a = s < 8 ? 64 * t : 64 * t + 32;            // k in [a, a + 31]
-    return cls == 0 ? a : cls == 1 ? (s == 0 ? 993 : 1024 - a - 31) : cls == 2 ? 1024 + a : (s == 0 ? 2017 : 2048 - a - 31);
+// ---- K7 tail (round 3): Z (E, O as pass 2 leaves them) -> quantised integers ---------------------------------------
+// profile1.py:21-40, p1tools.py:15-44.  The DCT pair step runs ONCE and leaves the frame's 4096 coefficients in the
+// registers that held E / O (lane 0's different pairing is resolved by one permutation up front, so all 16 jobs read the
+// same registers in every lane).  Band energies then need "lane owns consecutive bins", the quantiser "a wave store covers
+// consecutive bins"; the same registers serve both through one trip over the wave's LDS buffer:
+//   pass A  coefficients -> LDS in bin order (two rounds of 1024 bins x both channels: 2 x 32 rows of 32 doubles, rows
+//           padded to 34 as in `pslot`), read back as rows: lane (h, r) owns bins [1024 R + 32 r, + 32) of channel h.  A
+//           run of 32 bins touches at most three bands (launch condition), so three exec-masked running sums per lane
+//           replace the ~110 masked half-wave reductions of the round-2 kernel; the partial sums meet in a small
+//           [band][run] table and lane b (< 27) of each half adds band b's runs in order (deterministic).
+//   thresholds, their integer codes and the ramp steps: one band per lane (as before).
+//   pass B  per bin: band and position inside the band from two LDS byte / short tables (the bin index is lane + constant,
+//           so the reads need no address arithmetic), {threshold, step} of that band, numpy's linspace arithmetic, the
+//           float32-decided quantiser.  The integers go to the staging rows of the profile-0 kernel (32-bit codes) and
+//           leave as 16 coalesced 1 KiB stores.
+// The next unit's PCM DMA is issued between the two passes (pass A needs the whole 17 KiB buffer).
+// numpy's linspace has a second branch for a step that underflows to zero while the end points differ (p1tools.py:35-41
+// -> numpy.linspace `any_step_zero`).  It cannot be reached here: a threshold is either 0 (bands past the first empty
+// one) or >= min(ATH, 1) x loss >= 0.56 x 0.125, so two thresholds differ by 0, by one of them, or by >= one ulp of
+// 0.07 ~ 1.4e-17, and the band is at most 2048 bins wide: the quotient never underflows.
+struct P1K7Lds { const unsigned char* band; const int* edge; const double* floor_; const unsigned short* pk; const double* tqh; };
+__device__ __forceinline__ P1K7Lds p1w_k7_lds(unsigned char* smem) {
+    unsigned char* b = smem + kWaveLdsBytes + 16;
+    return {b, reinterpret_cast<const int*>(b + 2048), reinterpret_cast<const double*>(b + 2048 + 128), reinterpret_cast<const unsigned short*>(b + 2048 + 128 + 256),
+            reinterpret_cast<const double*>(b + 2048 + 128 + 256 + 4096)};
 }
-__host__ __device__ constexpr int wave_seg_hi(int s, int cls) {
-    const int t = s < 8 ? s : 15 - s, a = s < 8 ? 64 * t : 64 * t + 32;
-    return cls == 0 ? a + 31 : cls == 1 ? (s == 0 ? 1023 : 1024 - a) : cls == 2 ? 1024 + a + 31 : (s == 0 ? 2047 : 2048 - a);
+// float32 hardware transcendentals (one instruction each, about 1 ulp): seeds and decisions only, never a stored value
+__device__ __forceinline__ float k7_log2f(float v) {
+#ifdef FRAD_HOST_EMULATION
+    return log2f(v);
+#else
+    return __builtin_amdgcn_logf(v);
+#endif
 }
+__device__ __forceinline__ float k7_exp2f(float v) {
+#ifdef FRAD_HOST_EMULATION
+    return exp2f(v);
+#else
+    return __builtin_amdgcn_exp2f(v);
+#endif
+}
+__device__ __forceinline__ float k7_rcpf(float v) {
+#ifdef FRAD_HOST_EMULATION
+    return 1.0f / v;
+#else
+    return __builtin_amdgcn_rcpf(v);
+#endif
+}
+// r^0.4 = sqrt(r)^0.8 (p1tools.py:30, r = mean of the squared band), float64 to a few ulp without libm (whose constants the
+// compiler hoists out of the frame loop into registers it then spills): float32 seed, two Newton steps on y^5 = r^2, the
+// division inside a step by a float32 reciprocal (it scales a correction of relative size 1e-5 and 1e-11).
+__device__ __forceinline__ double k7_pow04(double r) {
+    const float rf = (float)r;
+    if (!(rf > 1e-30f)) return 0.0;                           // (far below every absolute threshold of hearing: the floor wins)
+    double y = (double)k7_exp2f(0.4f * k7_log2f(rf));
+    const double r2 = r * r;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double y2 = y * y, y4 = y2 * y2, y5 = y4 * y;
+        const double corr = (r2 - y5) * (double)k7_rcpf((float)y5);
+        y = fma(y * 0.2, corr, y);
+    }
+    return y;
+}
+// (int) round(dequant(log(max(t, 1)) / log(e / 2))) (profile1.py:38-40) = the number of table entries tqh[n] <= t: float32
+// estimate, then one exact step either way.  Beyond the table (band RMS above 3e8 in scaled units: not reachable with PCM of
+// 32 bits or fewer at the loss levels the reference offers) the float32 estimate stands.
+__device__ __forceinline__ int32_t k7_band_code(double t, const double* tqh) {
+    if (!(t > 1.0)) return 0;
+    const float v = k7_log2f((float)t) * 2.2585796f;          // ln 2 / ln(e / 2)
+    const float w = k7_exp2f(k7_log2f(v) * (4.0f / 3.0f));
+    if (!(w < 255.4f)) return w < 2.1e9f ? (int32_t)rintf(w) : 0x7fffffff;
+    int n = (int)rintf(w);
+    if (n > 0 && t < tqh[n - 1]) n -= 1;
+    else if (t >= tqh[n]) n += 1;
+    return n;
+}
+// (int) round(sign(x) |x / div * scale|^0.75), the per-bin quantiser of profile1.py:27-36.  Decided in float32 wherever that is
+// safe: the float32 value of |.|^0.75 carries a relative error below 1e-6 (two conversions, a reciprocal, two square roots,
+// three products), so unless it lies within 4e-6 y of a half-integer it rounds like the exact value.  The undecided bin (about
+// 1e-5 y of them) refines the float32 value by two Newton steps on y^4 div^3 = (|x| scale)^3 -- no division, no libm -- and,
+// should that still sit within 1e-12 of a half-integer h, compares (|x| scale)^3 with h^4 div^3 directly.
+template <bool EXACT>
+__device__ __forceinline__ int32_t k7_quantise(double x, double div, float scale, double scale_d, bool& undecided) {
+    const float xf = (float)x, df = (float)div;
+    const float mf = fabsf(xf) * k7_rcpf(df) * scale;
+    const float r = p1w_sqrtf(mf), yf = r * p1w_sqrtf(r);
+    const float fr = yf - floorf(yf);
+    int32_t qa = (int32_t)rintf(yf);
+    const bool und = !(fabsf(fr - 0.5f) > yf * 4e-6f + 1e-6f);   // (also NaN / Inf: div == 0, non-finite input)
+    if constexpr (!EXACT) undecided |= und;
+    else if (und) {
+        if (div == 0.0 || x == 0.0 || x != x || div != div) qa = 0;              // x / inf -> 0; NaN -> 0 like the conversion
+        else if (!(mf < 1e30f)) qa = 0x7fffffff;              // beyond int32 (the exact conversion saturates as well)
+        else {
+            const double a = fabs(x) * scale_d, a3 = a * a * a, d3 = div * div * div;
+            double y = (double)yf;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const double y2 = y * y, den = y2 * y2 * d3;
+                y = fma(y * 0.25, (a3 - den) * (double)k7_rcpf((float)den), y);
+            }
+            const double n = floor(y), hh = n + 0.5;
+            const double up = fabs(y - hh) > y * 1e-12 ? (y > hh ? 1.0 : 0.0) : (a3 > (hh * hh) * (hh * hh) * d3 ? 1.0 : 0.0);
+            const double qd = n + up;
+            qa = qd < 2147483647.0 ? (int32_t)qd : 0x7fffffff;
+        }
+    }
+    return xf < 0.0f ? -qa : qa;
+}
+// pk[(s * 32 + l) * 4 + cls] = (band j of the bin that lane l holds for job slot s, class cls) << 10 | position of the bin inside
+// band j; classes: X[k], X[M - k], X[M + k], X[N - k], k = wave_job_k(l, s) (lane 0 of slot 0: bins 0, 512, 1024, 1536).  One 8-byte
+// read per lane and job; both halves of the wave read the same entries.  After p1w_tables_to_lds + a block barrier.
+__device__ __forceinline__ int k7_bin_of(int s, int cls, int l) {
+    const int k = wave_job_k(l, s);
+    if (s == 0 && l == 0) return 512 * cls;
+    return cls == 0 ? k : cls == 1 ? 1024 - k : cls == 2 ? 1024 + k : 2048 - k;
+}
+__device__ __forceinline__ void p1w_k7_tables(unsigned char* smem) {
+    unsigned char* b = smem + kWaveLdsBytes + 16;
+    const int* edge = reinterpret_cast<const int*>(b + 2048);
+    unsigned short* pk = reinterpret_cast<unsigned short*>(b + 2048 + 128 + 256);
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) {
+        const int cls = i & 3, l = (i >> 2) & 31, s = i >> 7;
+        const int kb = k7_bin_of(s, cls, l), j = b[kb];
+        pk[i] = (unsigned short)(j < 26 ? ((kb - edge[j]) | (j << 10)) : 0);
+    }
+}
+constexpr int kK7PlaneBytes = 32 * 34 * 8;            // one channel's 1024 coefficients of a round (8704 B; two planes = the wave's buffer)
+constexpr int kK7RecOff = 16384;                      // {threshold, step} per band and half: 2 x 32 x 16 B, above the PCM landing zone
+constexpr int kK7Slots = 16;                          // runs of 32 bins per band in the gather table (launch condition)
+static_assert(2 * kK7PlaneBytes <= kWaveBufBytes && kK7RecOff + 1024 <= kWaveBufBytes && 2 * 27 * kK7Slots * 8 <= 8192, "K7 LDS plan");
 
-// K7 tail: Z (E, O as pass 2 leaves them) -> DCT pair step -> band energies -> thresholds -> quantised integers.
-// The pair step is cheap next to a second set of 64 registers per lane, so it runs twice: once for the energies (segmented
-// half-wave sums: a job's 32 bins per channel are consecutive, the bands they touch are wave-uniform), once for the quantiser.
-template <int CC, typename T>
-__device__ __forceinline__ void wave_p1_quantise(const cx<T> (&E)[16], const cx<T> (&O)[16], const cx<T>* ltab, unsigned char* smem,
-                                                 unsigned char* wbuf, int32_t* __restrict__ q, const P1Wave& pw, const Geom& g,
-                                                 long long u, int lane) {
+template <int CC, typename T, typename DMA>
+__device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], const cx<T>* ltab, unsigned char* smem,
+                                             unsigned char* wbuf, unsigned char* __restrict__ qout, const P1Wave& pw, const Geom& g,
+                                             long long u, int lane, DMA&& dma_next) {
     constexpr int M = 1024, N = 2048;
     const int h = lane >> 5, l = lane & 31;
     const bool lane0 = (l == 0);
     const long long f = CC == 2 ? u : 2 * u + h;
     const bool live = f < g.n_frames;
     const int c = CC == 2 ? h : 0;
-    const P1Lds2 p1t = p1w_lds(smem);
-    double* thr = reinterpret_cast<double*>(wbuf); double* stp = thr + 64;
+    const P1K7Lds t = p1w_k7_lds(smem);
     auto sel = [&](cx<T> a, cx<T> b) { return cx<T>{lane0 ? a.x : b.x, lane0 ? a.y : b.y}; };
-    // X of job slot s: x[0] = X[k], x[1] = X[M - k], x[2] = X[M + k], x[3] = X[N - k] (the profile-0 arithmetic); lane 0 of
-    // slot 0 (k = 0) has X[0] and, in x[2], X[M]; its x[1], x[3] name no bin
-    auto job = [&](int s, cx<T> wk, cx<T> gk, T (&x)[4]) {
-        const cx<T> zk = s < 8 ? E[s] : O[15 - s];
-        const cx<T> zm = s < 8 ? sel(E[(16 - s) & 15], O[15 - s]) : sel(O[s], E[s]);
-        const cx<T> zp = conj(zm);
-        const cx<T> p = cmul(zk + zp, wk), qq = cmul(zk - zp, gk);
-        const cx<T> S = p + qq, D = p - qq;
-        const T xm = (D.x - D.y) * K<T>::s2, xp = (D.x + D.y) * K<T>::s2;
-        x[0] = S.x; x[1] = xm; x[2] = (s == 0 && lane0) ? xm : xp; x[3] = -S.y;
-    };
-    cx<T> ptab[2][2];
-    auto ptab_load = [&](int s) {
-        ptab[s & 1][0] = ltab[WaveLayout::PW + s * 32 + l];
-        ptab[s & 1][1] = ltab[WaveLayout::PG + s * 32 + l];
-    };
-    // The 32 bins a half-wave holds per (slot, class) are consecutive, so the bands they touch are the same for every
-    // lane and both channels: band range and edges are wave-uniform (scalar registers), membership is two compares, and
-    // nothing is gathered per lane.
-    // The lookups themselves are lane reads of three registers filled once per unit -- lane 4 s + cls holds the segment's
-    // first and last band, lane b edge[b], lanes 0 / 1 the bands of bins 512 / 1536: a wave-uniform LDS read in the middle
-    // of every segment costs a full LDS round trip plus a readfirstlane each, ~400 times per frame.
-    const int vseg = (int)p1t.band[wave_seg_lo(lane >> 2, lane & 3)] | ((int)p1t.band[wave_seg_hi(lane >> 2, lane & 3)] << 8);
-    const int vedge = p1t.edge[l];                            // (edge[28 .. 31]: padding, never selected)
-    const int vmid = (int)p1t.band[512 + 1024 * (lane & 1)];
-    auto seg_bands = [&](int s, int cls, int& blo, int& bhi) {
-        const int v = wave_read_lane(vseg, 4 * s + cls);
-        blo = v & 255; bhi = v >> 8;
-        if (bhi > 25) bhi = 25;                               // 255: beyond the last band start -- no band there
-    };
-    // ---- pass A: band energies sum((X * scale)^2) (p1tools.py:21-29); lane b of each half accumulates band b ----------
-    double accreg = 0.0;
-    ptab_load(0);
-    FRAD_FENCE();
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        if (s + 1 < 16) ptab_load(s + 1);
-        FRAD_FENCE();
-        T x[4];
-        job(s, ptab[s & 1][0], ptab[s & 1][1], x);
-        const int kq = wave_job_k(l, s);
-#pragma unroll
-        for (int cls = 0; cls < 4; ++cls) {
-            const bool valid = !(s == 0 && lane0 && (cls & 1));
-            const int kb = cls == 0 ? kq : cls == 1 ? M - kq : cls == 2 ? M + kq : N - kq;
-            const T v = x[cls] * pw.scale;
-            const T v2 = valid ? v * v : 0.0;
-            int blo, bhi;
-            seg_bands(s, cls, blo, bhi);
-#ifdef FRAD_X_P1_NOSUM
-            accreg += v2; (void)blo; (void)bhi; (void)kb;
-#else
-            if (blo <= bhi) {
-                int ea = wave_read_lane(vedge, blo);
-                for (int b = blo; b <= bhi; ++b) {
-                    const int eb = wave_read_lane(vedge, b + 1);
-                    double s0, s1;
-                    half_wave_sum_f64((kb >= ea && kb < eb) ? v2 : 0.0, s0, s1);
-                    accreg += (l == b) ? (h ? s1 : s0) : 0.0;
-                    ea = eb;
-                }
-            }
-#endif
-        }
-        FRAD_FENCE();
-    }
-    T xs[2] = {0.0, 0.0};                                         // lane 0: the self-paired bin k = 512 -> X[512], X[1536]
+    // ---- the self-paired bin k = 512 (lane 0's E[8]) and lane 0's pairing --------------------------------------------
+    T xs0, xs1;
     {
         const cx<T> zk = E[8], zp = conj(E[8]);
         const cx<T> p = cmul(zk + zp, ltab[WaveLayout::TW1 + 0]), qq = cmul(zk - zp, ltab[WaveLayout::TW1 + 1]);
         const cx<T> S = p + qq;
-        xs[0] = S.x; xs[1] = -S.y;
+        xs0 = S.x; xs1 = -S.y;
+    }
+    // job s reads zk = (s < 8 ? E[s] : O[15 - s]) and zm = (s < 8 ? O[15 - s] : E[s]); lane 0 pairs E[s] with E[16 - s] and
+    // O[15 - s] with O[s] instead (see wave_fwd_body), i.e. it wants E[8 .. 15] <- O[8 .. 15] and O[j] <- E[(j + 1) & 15], j >= 8
+    {
+        cx<T> e2[8], o2[8];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int jb = wave_read_lane(vmid, i);
-            const T v = xs[i] * pw.scale;
-            double s0, s1;
-            half_wave_sum_f64(lane0 ? v * v : 0.0, s0, s1);
-            accreg += (jb < 26 && l == jb) ? (h ? s1 : s0) : 0.0;
+        for (int j = 8; j < 16; ++j) { e2[j - 8] = sel(O[j], E[j]); o2[j - 8] = sel(E[(j + 1) & 15], O[j]); }
+#pragma unroll
+        for (int j = 8; j < 16; ++j) { E[j] = e2[j - 8]; O[j] = o2[j - 8]; }
+    }
+    // ---- pair step, once: X[s][0..3] = X[k], X[M - k], X[M + k], X[N - k], k = wave_job_k(l, s); lane 0 of slot 0 (k = 0)
+    //      carries X[0], X[512], X[M], X[1536] (the self-paired bins take the places of the two bins it does not have)
+    T X[16][4];
+    // plane address of local bin b (0 .. 1023): row b >> 5 (pitch 34 doubles), column b & 31
+    auto paddr = [&](int b) -> int { return ((b >> 5) * 34 + (b & 31)) * 8; };
+    unsigned char* plw = wbuf + h * kK7PlaneBytes;
+    {
+        cx<T> ptab[2][2];
+        auto ptab_load = [&](int s) {
+            ptab[s & 1][0] = ltab[WaveLayout::PW + s * 32 + l];
+            ptab[s & 1][1] = ltab[WaveLayout::PG + s * 32 + l];
+        };
+        ptab_load(0);
+        FRAD_FENCE();
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if (s + 1 < 16) ptab_load(s + 1);
+            FRAD_FENCE();
+            const cx<T> zk = s < 8 ? E[s] : O[15 - s];
+            const cx<T> zm = s < 8 ? O[15 - s] : E[s];
+            const cx<T> zp = conj(zm);
+            const cx<T> p = cmul(zk + zp, ptab[s & 1][0]), qq = cmul(zk - zp, ptab[s & 1][1]);
+            const cx<T> S = p + qq, D = p - qq;
+            const T xm = (D.x - D.y) * K<T>::s2, xp = (D.x + D.y) * K<T>::s2;
+            if (s == 0) { X[0][0] = S.x; X[0][1] = lane0 ? xs0 : xm; X[0][2] = lane0 ? xm : xp; X[0][3] = lane0 ? xs1 : -S.y; }
+            else { X[s][0] = S.x; X[s][1] = xm; X[s][2] = xp; X[s][3] = -S.y; }
+            // round 0 of pass A: bins below M go to the plane as they appear
+            const int k = wave_job_k(l, s);
+            const int kb1 = (s == 0 && lane0) ? 512 : M - k;
+            *reinterpret_cast<T*>(plw + paddr(k)) = X[s][0];
+            *reinterpret_cast<T*>(plw + paddr(kb1)) = X[s][1];
+            FRAD_FENCE();
         }
     }
-    // ---- thresholds (p1tools.py:18-33), their quantised form (profile1.py:38-40), ramp steps (p1tools.py:35-41) ----
-    if (l < 27) {
-        const int b = l, bins = p1t.edge[b + 1] - p1t.edge[b];
-        double t = 0.0;
-#ifdef FRAD_X_P1_NOPOW
-        t = accreg + 1.0; (void)bins;
-        thr[h * 32 + b] = t;
-        if (live) pw.tq_out[(f * 27 + b) * CC + c] = (int32_t)t;
-#else
-        if (b < pw.nb_used) t = p1_band_threshold(accreg, bins, p1t.floor_[b], pw.loss, 0);
-        thr[h * 32 + b] = t;
-        if (live) {
-            const double v = log(t > 1.0 ? t : 1.0) / log(2.718281828459045 / 2);
-            pw.tq_out[(f * 27 + b) * CC + c] = (int32_t)rint(copysign(pow(fabs(v), 1.0 / 0.75), v));
+    // ---- pass A: band energies --------------------------------------------------------------------------------------
+    // per-launch constants of this lane's two runs (g = 32 R + l): first band, offsets of the (at most two) band edges inside
+    // the run (32 = none), slot of the run in its first band's table row
+    int rb0[2], rr1[2], rr2[2], rsl[2];
+#pragma unroll
+    for (int R = 0; R < 2; ++R) {
+        const int gq = 32 * R + l, b0 = t.band[32 * gq];
+        const int e1 = t.edge[b0 + 1] - 32 * gq, e2 = t.edge[b0 + 2] - 32 * gq;     // (edge[] is clipped to N and padded with N)
+        rb0[R] = b0; rr1[R] = e1 < 32 ? e1 : 32; rr2[R] = e2 < 32 ? e2 : 32; rsl[R] = gq - (t.edge[b0] >> 5);
+    }
+    double part[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+    auto run_sums = [&](auto rtag) {
+        constexpr int R = decltype(rtag)::value;
+        const v2d* row = reinterpret_cast<const v2d*>(plw + l * 272);
+        const int r1 = rr1[R], r2 = rr2[R];
+        double a = 0.0, b = 0.0, cc = 0.0;
+        v2d buf[2][4];
+        auto fetch = [&](int bq) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) buf[bq & 1][i] = row[4 * bq + i];
+        };
+        fetch(0);
+        FRAD_FENCE();
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) {
+            if (bq < 3) fetch(bq + 1);
+            FRAD_FENCE();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int idx = 8 * bq + 2 * i + e;
+                    const double x = buf[bq & 1][i][e];
+                    if (idx < r1) a = fma(x, x, a); else if (idx < r2) b = fma(x, x, b); else cc = fma(x, x, cc);
+                }
+            }
+            FRAD_FENCE();
         }
+        part[R][0] = a; part[R][1] = b; part[R][2] = cc;
+    };
+    team_sync<64>();
+    run_sums(ic<0>{});
+    team_sync<64>();                                              // round 0 read: the planes take the upper half of the bins
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int k = wave_job_k(l, s);
+        const int kb3 = (s == 0 && lane0) ? 512 : M - k;          // local bin of N - k (lane 0, slot 0: 1536)
+        *reinterpret_cast<T*>(plw + paddr(k)) = X[s][2];
+        *reinterpret_cast<T*>(plw + paddr(kb3)) = X[s][3];
+    }
+    team_sync<64>();
+    run_sums(ic<1>{});
+#ifndef FRAD_HOST_EMULATION
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // every plane read has returned: the DMA may land in [8 KiB, 16 KiB)
 #endif
+    team_sync<64>();
+    FRAD_FENCE();
+    dma_next();
+    FRAD_FENCE();
+    // partial sums -> table [half][band][run slot]; lane b adds band b's runs
+    double* tab = reinterpret_cast<double*>(wbuf) + h * (27 * kK7Slots);
+#pragma unroll
+    for (int R = 0; R < 2; ++R) {
+        tab[rb0[R] * kK7Slots + rsl[R]] = part[R][0];
+        if (rr1[R] < 32) tab[(rb0[R] + 1) * kK7Slots] = part[R][1];
+        if (rr2[R] < 32) tab[(rb0[R] + 2) * kK7Slots] = part[R][2];
+    }
+    team_sync<64>();
+    double* rec = reinterpret_cast<double*>(wbuf + kK7RecOff) + h * 64;     // rec[2 b] = threshold, rec[2 b + 1] = ramp step
+    if (l < 27) {
+        const int b = l, e0 = t.edge[b], e1 = t.edge[b + 1], bins = e1 - e0;
+        const int cnt = bins > 0 ? ((e1 - 1) >> 5) - (e0 >> 5) + 1 : 0;
+        const v2d* tr = reinterpret_cast<const v2d*>(tab + b * kK7Slots);
+        double energy = 0.0;
+#pragma unroll
+        for (int i = 0; i < kK7Slots / 2; ++i) {
+            const v2d v = tr[i];
+            energy += (2 * i < cnt) ? v[0] : 0.0;
+            energy += (2 * i + 1 < cnt) ? v[1] : 0.0;
+        }
+        energy *= pw.scale * pw.scale;                            // sum((X scale)^2): the scale is a power of two
+        double th = 0.0;
+        if (b < pw.nb_used) {                                     // p1tools.py:30-31
+            const double sfq = k7_pow04(energy / (double)bins), fl = t.floor_[b];
+            th = (fl > sfq ? fl : sfq) * pw.loss;
+        }
+        rec[2 * b] = th;
+        if (live) pw.tq_out[(f * 27 + b) * CC + c] = k7_band_code(th, t.tqh);
     }
     team_sync<64>();
     if (l < 27) {
         double st = 0.0;
-        if (l < 26) { const int num = p1t.edge[l + 1] - p1t.edge[l]; if (num > 0) st = (thr[h * 32 + l + 1] - thr[h * 32 + l]) / (double)num; }
-        stp[h * 32 + l] = st;
+        if (l < 26) { const int num = t.edge[l + 1] - t.edge[l]; if (num > 0) st = (rec[2 * l + 2] - rec[2 * l]) / (double)num; }
+        rec[2 * l + 1] = st;
     }
     team_sync<64>();
-    // ---- pass B: per-bin divide + power-law quantiser (profile1.py:27-36), 256 contiguous bytes per store ----------
-    int32_t* qf = q + (live ? f : 0) * (long long)N * CC + c;
-    auto quant_div = [&](T x, double div) -> int32_t { return p1w_quantise(x, div, pw.scale); };
-    // threshold ramp at bin kb of band b (np.linspace without its end point; numpy's branch for a vanishing step)
-    auto ramp = [&](int b, int ea, int eb, int kb) -> double {
-        const double t0 = thr[h * 32 + b], st = stp[h * 32 + b], i = (double)(kb - ea);
-        double y = i * st;
-        if (st == 0.0) { const double d = thr[h * 32 + b + 1] - t0; if (d != 0.0) y = (i / (double)(eb - ea)) * d; }   // see p1w_spread
-        return y + t0;
-    };
-    ptab_load(0);
+    // ---- pass B: quantiser (profile1.py:27-36), integers through the profile-0 staging rows ---------------------------
+    constexpr int NB = 4, NG = 4, JPG = 4, BPC = 128, ES = CC * NB;
+    int hq = h, lq = l;
+    FRAD_OPAQUE(hq); FRAD_OPAQUE(lq);
+    unsigned char* stg = wbuf + (CC == 2 ? hq * NB : hq * 512);
+    unsigned char* dstf = qout + (live ? f : 0) * g.payload_stride + (CC == 2 ? lane : l) * 16;
+    const int la = lq * ES, lb = (lane0 ? 32 : 64 - lq) * ES;
+    auto row_of = [&](int gi, int cls) -> unsigned char* { return stg + (gi & 1) * 4096 + cls * 1024; };
+    auto job_slot = [](int gi, int i) -> int { const int tt = gi * (JPG / 2) + (i >> 1); return (i & 1) ? 15 - tt : tt; };
+    const v2d* recv = reinterpret_cast<const v2d*>(rec);
+    const v2u* pk2 = reinterpret_cast<const v2u*>(t.pk) + l;      // entry of (slot s, this lane): pk2[32 s]
+    const float scale_f = (float)pw.scale;
+    auto code_store = [&](unsigned char* p, int32_t v) { *reinterpret_cast<int32_t*>(p) = v; };
+    v2u ent[2];
+    auto ent_load = [&](int gi, int i) { ent[i & 1] = pk2[32 * job_slot(gi, i)]; };
+    ent_load(NG - 1, 0);
     FRAD_FENCE();
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        if (s + 1 < 16) ptab_load(s + 1);
-        FRAD_FENCE();
-        T x[4];
-        job(s, ptab[s & 1][0], ptab[s & 1][1], x);
-        const int kq = wave_job_k(l, s);
+    for (int gi = NG - 1; gi >= 0; --gi) {
+        bool undecided = false;
+        // the group's four jobs; EXACT = false: float32 decisions, `undecided` collects the bins that float32 cannot decide;
+        // EXACT = true (run only when some lane has one): every bin again with the exact fall-back, same stores
+        auto group = [&](auto exact_tag) {
+            constexpr bool EXACT = decltype(exact_tag)::value;
+            if constexpr (EXACT) ent_load(gi, 0);
 #pragma unroll
-        for (int cls = 0; cls < 4; ++cls) {
-            const bool valid = !(s == 0 && lane0 && (cls & 1));
-            const int kb = cls == 0 ? kq : cls == 1 ? M - kq : cls == 2 ? M + kq : N - kq;
-            int blo, bhi;
-            seg_bands(s, cls, blo, bhi);
-            double div = 0.0;                                    // bins beyond the last band start divide by 0 -> 0
-#ifdef FRAD_X_P1_NORAMP
-            div = thr[h * 32 + (blo & 15)] + (double)bhi;
-#else
-            if (blo <= bhi) {
-                int ea = wave_read_lane(vedge, blo);
-                for (int b = blo; b <= bhi; ++b) {
-                    const int eb = wave_read_lane(vedge, b + 1);
-                    const double d = ramp(b, ea, eb, kb);
-                    div = (kb >= ea && kb < eb) ? d : div;
-                    ea = eb;
+            for (int i = 0; i < JPG; ++i) {
+                const int s = job_slot(gi, i);
+                const v2u e2 = ent[i & 1];
+                const uint32_t en[4] = {e2[0] & 0xffffu, e2[0] >> 16, e2[1] & 0xffffu, e2[1] >> 16};
+                v2d rc[4];
+#pragma unroll
+                for (int cq = 0; cq < 4; ++cq) rc[cq] = recv[en[cq] >> 10];
+                if (i + 1 < JPG) ent_load(gi, i + 1); else if (gi > 0 && !EXACT) ent_load(gi - 1, 0);
+                FRAD_FENCE();
+                int32_t qv[4];
+#pragma unroll
+                for (int cq = 0; cq < 4; ++cq) {                  // np.linspace without its end point: t0 + i * step (two roundings)
+                    const double y = (double)(int)(en[cq] & 1023u) * rc[cq][1];
+                    qv[cq] = k7_quantise<EXACT>(X[s][cq], y + rc[cq][0], scale_f, pw.scale, undecided);
                 }
+                const int tt = s < 8 ? s : 15 - s, tl = tt - gi * (JPG / 2);
+                const int offa = 64 * tl * ES + (s < 8 ? la : lb);
+                unsigned char* pa = row_of(gi, 0) + offa;
+                unsigned char* pc = row_of(gi, 2) + offa;
+                unsigned char* pb = row_of(gi, 1) + BPC * ES - offa;
+                unsigned char* pd = row_of(gi, 3) + BPC * ES - offa;
+                code_store(pa, qv[0]);
+                code_store(pc, qv[2]);
+                if (s == 0) {
+                    // lane 0 holds k = 0: X[0] (class A) and X[M] (first bin of class C); its bins 512 / 1536 were stored with the
+                    // rows of group NG - 1 (below); here it repeats X[0]
+                    code_store(lane0 ? pa : pb, lane0 ? qv[0] : qv[1]);
+                    code_store(lane0 ? pa : pd, lane0 ? qv[0] : qv[3]);
+                } else if (tl == 0 && s < 8) {                    // lane 0's M - k and N - k open the next-higher piece (group gi - 1)
+                    code_store(lane0 ? row_of(gi - 1, 1) : pb, qv[1]);
+                    code_store(lane0 ? row_of(gi - 1, 3) : pd, qv[3]);
+                } else {
+                    code_store(pb, qv[1]);
+                    code_store(pd, qv[3]);
+                }
+                FRAD_FENCE();
             }
-#endif
-#ifdef FRAD_X_P1_NOQUANT
-            const int32_t qv = (int32_t)(x[cls] * div);
-#else
-            const int32_t qv = quant_div(x[cls], div);
-#endif
-            if (valid && live) *FRAD_GPTR(int32_t, qf + (long long)kb * CC) = qv;
+            if (gi == NG - 1) {                                   // lane 0: bins 512 and 1536 (its slot-0 values of classes 1 and 3)
+                const v2u e2 = pk2[0];
+                const uint32_t e1 = e2[0] >> 16, e3 = e2[1] >> 16;
+                const v2d r1 = recv[e1 >> 10], r3 = recv[e3 >> 10];
+                const int32_t q1 = k7_quantise<EXACT>(X[0][1], (double)(int)(e1 & 1023u) * r1[1] + r1[0], scale_f, pw.scale, undecided);
+                const int32_t q3 = k7_quantise<EXACT>(X[0][3], (double)(int)(e3 & 1023u) * r3[1] + r3[0], scale_f, pw.scale, undecided);
+                if (lane0) { code_store(row_of(NG - 1, 1), q1); code_store(row_of(NG - 1, 3), q3); }
+            }
+        };
+        group(ic<0>{});
+        if (wave_any(undecided)) { group(ic<1>{}); if (gi > 0) ent_load(gi - 1, 0); }
+        FRAD_FENCE();
+        team_sync<64>();
+        FRAD_FENCE();
+        {
+            v4u row[4];
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) row[cq] = *reinterpret_cast<const v4u*>(wbuf + (gi & 1) * 4096 + cq * 1024 + lane * 16);
+            team_sync<64>();
+            const int oa = gi * 512 * CC, ob = 1024 * ES - (gi + 1) * 512 * CC, oc = 1024 * ES + gi * 512 * CC, od = 2048 * ES - (gi + 1) * 512 * CC;
+            const int off[4] = {oa, ob, oc, od};
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq)
+                if (CC == 2 || live) stream_store(dstf + off[cq], row[cq]);
         }
         FRAD_FENCE();
-    }
-    auto quant = [&](T x, int kbin) -> int32_t { return quant_div(x, p1w_spread(p1t, thr, stp, h, kbin)); };
-    if (lane0 && live) {
-        *FRAD_GPTR(int32_t, qf + 512LL * CC) = quant(xs[0], 512);
-        *FRAD_GPTR(int32_t, qf + 1536LL * CC) = quant(xs[1], 1536);
     }
 }
 #ifndef FRAD_WAVE_DMA_AUX
@@ -613,6 +824,7 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
     long long u = ub + wv;
     if (u < ue) dma_in(u);
     __syncthreads();                                          // tables and counter are in LDS (the barrier's fence also retires the first DMA)
+    if constexpr (MODE == 1) { p1w_k7_tables(smem); __syncthreads(); }
     for (int i = (wv * 8 + (int)(blockIdx.x & 7)) * g.cg; i > 0; --i) FRAD_WAVE_SLEEP(1);      // start stagger (g.cg x 64 cycles per step; 0 = off)
     FRAD_STAMP_DECL;
     while (u < ue) {
@@ -635,7 +847,7 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
 #ifndef FRAD_HOST_EMULATION
             // this unit's DMA was issued before the previous unit's 4 NB row stores: vector-memory operations retire
             // in order, so at most that many may still be in flight
-            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(MODE == 1 ? 60 : 4 * NB) : "memory");   // (profile 1: 67 stores follow the DMA)
+            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(4 * NB) : "memory");   // (profile 1: the 16 row stores follow the DMA, and one store of threshold codes before them)
 #endif
             FRAD_STAMP(0);
             team_sync<64>();
@@ -798,8 +1010,9 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         team_sync<64>();
         FRAD_STAMP(3);
         FRAD_FENCE();
-        dma_in(next < ue ? next : ub);                         // raw landing zone is free from here on (no branch; a wave's last DMA re-reads the
+        if constexpr (MODE != 1) dma_in(next < ue ? next : ub);    // raw landing zone is free from here on (no branch; a wave's last DMA re-reads the
                                                                //  block's first unit, which its six neighbours hit in L2 -- never consumed)
+                                                               //  (profile 1: issued inside the tail, whose first pass uses the whole buffer)
         FRAD_FENCE();
         // ---- pair-step tables of the first group, then pass 2 proper -----------------------------------
         // group g (processed from NG - 1 down to 0) holds jobs t and 15 - t for t in [g JPG / 2, (g + 1) JPG / 2)
@@ -821,7 +1034,7 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         dft<16, false>(O);                                     // O[u] = Z[b + 32 (2 u + 1)]
         FRAD_FENCE();
         if constexpr (MODE == 1) {
-            wave_p1_quantise<CC>(E, O, ltab, smem, wbuf, reinterpret_cast<int32_t*>(payload), pw, g, u, lane);
+            wave_p1_tail<CC>(E, O, ltab, smem, wbuf, payload, pw, g, u, lane, [&]() { dma_in(next < ue ? next : ub); });
         } else {
         ptab_load(NG - 1, 0);
         FRAD_FENCE();
