@@ -298,13 +298,33 @@ int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32
     if (rc != FRAD_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Geom g = p1_geom(n_frames, N, C, N, N, FRAD_PCM_F64LE, 0);
-    {
+    FastCfg c = fast_cfg(N, C, false);
+    if (N == 2048 && C <= 2 && n_frames < 0x7fffffffLL && p1_fast_fits(c, N, C)) {
+        // N = 2048, one or two channels: the table-driven wave kernel, then the exact kernel over the frames it marked (a band
+        // code outside [0, 256) or |q| >= 256: none in a sane stream).  The list is stream-ordered scratch: count + one slot per frame.
+        struct Redo { hipStream_t s; int* p = nullptr; ~Redo() { if (p) (void)hipFreeAsync(p, s); } } redo{s};
+        if (hipMallocAsync(reinterpret_cast<void**>(&redo.p), sizeof(int) * (size_t)(n_frames + 1), s) != hipSuccess) return FRAD_E_NOMEM;
+        P1CHK(hipMemsetAsync(redo.p, 0, sizeof(int), s));
         P1Wave pw = wave_tables(tb, N);
         pw.tq_in = tq;
         pw.deq = deq_table();
-        if (launch_p1_inv_wave(s, q, pcm_out, g, pw, p1_unit_neg)) { P1CHK(hipGetLastError()); return FRAD_OK; }
+        pw.redo = redo.p;
+        if (launch_p1_inv_wave(s, q, pcm_out, g, pw, p1_unit_neg)) {
+            P1CHK(hipGetLastError());
+            const int M = 1 << c.log2m;
+            const size_t lds = (size_t)C * M * 16 + p1_scratch_bytes(C, N);
+            Tables t; rc = get_tables(c.log2m, false, t);
+            if (rc != FRAD_OK) return rc;
+            Geom gr = g; gr.fpb = 1;
+            const int threads = C * c.team;
+            const cx<double>* tw = static_cast<const cx<double>*>(t.tw); const cx<double>* post = static_cast<const cx<double>*>(t.post);
+            const unsigned grid = (unsigned)(n_frames < 256 ? n_frames : 256);
+            allow_lds(k_p1_inv_redo<10, 256>, lds);
+            hipLaunchKernelGGL((k_p1_inv_redo<10, 256>), dim3(grid), dim3(threads), lds, s, q, tq, pcm_out, tw, post, gr, tb, redo.p);
+            P1CHK(hipGetLastError());
+            return FRAD_OK;
+        }
     }
-    FastCfg c = fast_cfg(N, C, false);
     if (p1_fast_fits(c, N, C)) {
         const int M = 1 << c.log2m;
         const size_t lds = (size_t)c.fpb * C * M * 16 + p1_scratch_bytes(c.fpb * C, N);

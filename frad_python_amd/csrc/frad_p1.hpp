@@ -216,6 +216,33 @@ k_p1_inv(const int32_t* __restrict__ q, const int32_t* __restrict__ tq, double* 
     store_pcm_f64<SH, true>(0, out, g, f0, nfl, SLOTS);
 }
 
+// The frames the table-driven wave kernel (k_p1_inv_wave) marked: redo[0] = count, redo[1 + i] = frame index.  One frame per
+// block pass (launch with g.fpb = 1), the exact arithmetic of k_p1_inv; runs behind the wave kernel on the same stream and
+// overwrites its output for those frames.
+template <int LOG2M, int MAXT>
+__global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? 2 : 1))
+k_p1_inv_redo(const int32_t* __restrict__ q, const int32_t* __restrict__ tq, double* __restrict__ out,
+              const cx<double>* __restrict__ tw, const cx<double>* __restrict__ post, Geom g, P1Tables tb, const int* __restrict__ redo) {
+    constexpr int M = 1 << LOG2M, TEAM = Plan<LOG2M>::TEAM, SLOTS = padded_slots(M), SH = Plan<LOG2M>::SH;
+    FRAD_DYN_SMEM(smem);
+    const int count = redo[0];
+    if ((int)blockIdx.x >= count) return;
+    const int cf = threadIdx.x / TEAM, t = threadIdx.x - cf * TEAM;
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem) + (long long)cf * SLOTS;
+    p1_tables_to_lds(smem + g.C * SLOTS * 16, g.C, tb, g.N);
+    for (int i = blockIdx.x; i < count; i += gridDim.x) {
+        const long long f0 = redo[1 + i];
+        p1_dequantise<SH>(0, g.C * SLOTS * 16, SLOTS, tb.scale, g, f0, 1, q, tq, 0, g.C, g.C);
+        __syncthreads();
+        int tt = t; FRAD_OPAQUE(tt);
+        dct_pre_inverse<double, LOG2M>(buf, tt, post);
+        fft_team<double, LOG2M, true>(buf, tt, tw);
+        __syncthreads();
+        store_pcm_f64<SH, true>(0, out, g, f0, 1, SLOTS);
+        __syncthreads();
+    }
+}
+
 // Frames whose channels exceed a CU's LDS: one frame per block, g.cg channels per pass (stage / transform / quantise
 // per group; the quantiser works channel by channel, so groups are independent).
 template <int LOG2M, int LG, int MAXT>

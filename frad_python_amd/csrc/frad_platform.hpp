@@ -21,6 +21,8 @@
 #define FRAD_GPTR(T, p) ((__attribute__((address_space(1))) T*)(p))
 #define FRAD_GCPTR(T, p) ((const __attribute__((address_space(1))) T*)(p))
 #define FRAD_OPAQUE(x) asm volatile("" : "+v"(x))
+// the value is complete at this point of the instruction stream: pure arithmetic otherwise floats across scheduling fences
+#define FRAD_PIN(x) asm volatile("" : "+v"(x))
 // workgroup barrier that only waits for this wave's LDS traffic: __syncthreads() also drains vmcnt,
 // i.e. every global load and store in flight, which is exactly what a pipelined kernel must not do
 #define FRAD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")

@@ -212,43 +212,56 @@ struct P1Wave {
     int32_t* tq_out;             // K7: [n_frames, 27, C]
     const double* tqh;           // K7: device table [256]: (e/2)^((n + 1/2)^0.75), the thresholds at which the band code of
                                  // profile1.py:38-40 steps from n to n + 1 (correctly rounded)
+    int* redo;                   // K8: redo[0] = number of frames the table-driven kernel could not take (a band code outside
+                                 // [0, 256) or |q| >= 256: corrupt or extremely loud frames), redo[1 + i] = their indices; the
+                                 // exact one-shot kernel decodes them again behind it (k_p1_inv_redo)
 };
 struct P1None {};
-// after the work counter: band_of[2048] | edge[32] | floor[32] | K8: deq[256] | thr[256] doubles; K7: kme[2048] shorts | tqh[256] doubles
+// after the work counter, K7: band_of[2048] | edge[32] | floor[32] | pk[2048] shorts | tqh[256] doubles; K8: see P1K8Lds
 constexpr int kP1BlockBytes = 2048 + 32 * 4 + 32 * 8 + 2048 * 2 + 256 * 8;
 constexpr int kWaveLdsBytesP1 = kWaveLdsBytes + 16 + kP1BlockBytes;
 static_assert(kWaveLdsBytesP1 <= 160 * 1024, "a CU's LDS");
-struct P1Lds2 { const unsigned char* band; const int* edge; const double* floor_; const double* deq; };
-__device__ __forceinline__ P1Lds2 p1w_lds(unsigned char* smem) {
-    unsigned char* b = smem + kWaveLdsBytes + 16;
-    return {b, reinterpret_cast<const int*>(b + 2048), reinterpret_cast<const double*>(b + 2048 + 128), reinterpret_cast<const double*>(b + 2048 + 128 + 256)};
-}
-__device__ __forceinline__ void p1w_tables_to_lds(unsigned char* smem, const P1Wave& pw) {
+__device__ __forceinline__ void p1w_tables_to_lds(unsigned char* smem, const P1Wave& pw) {      // K7
     unsigned char* b = smem + kWaveLdsBytes + 16;
     for (int i = threadIdx.x; i < 512; i += blockDim.x) reinterpret_cast<uint32_t*>(b)[i] = reinterpret_cast<const uint32_t*>(pw.band_of)[i];
     if (threadIdx.x < 28) reinterpret_cast<int*>(b + 2048)[threadIdx.x] = pw.edge[threadIdx.x];
     if (threadIdx.x < 27) reinterpret_cast<double*>(b + 2048 + 128)[threadIdx.x] = pw.floor_[threadIdx.x];
-    if (pw.deq != nullptr) for (int i = threadIdx.x; i < 512; i += blockDim.x) reinterpret_cast<double*>(b + 2048 + 128 + 256)[i] = pw.deq[i];
     if (pw.tqh != nullptr) for (int i = threadIdx.x; i < 256; i += blockDim.x) reinterpret_cast<double*>(b + 2048 + 128 + 256 + 4096)[i] = pw.tqh[i];
 }
-// per-wave scratch at the start of the wave's buffer: thr[2][32] | stp[2][32] | acc[2][32] doubles (index h * 32 + band)
-__device__ __forceinline__ double p1w_spread(const P1Lds2& t, const double* thr, const double* stp, int h, int k) {
-    const int j = t.band[k];
-    if (j >= 26) return 0.0;
-    const int a = t.edge[j];
-    const double i = (double)(k - a), st = stp[h * 32 + j], t0 = thr[h * 32 + j];
-    double y = i * st;
-    if (st == 0.0) {                                          // equal neighbours (common: y stays +0) or a step that underflowed:
-        const double d = thr[h * 32 + j + 1] - t0;            // numpy's denormal-safe branch (p1tools.py:35-41), the division
-        if (d != 0.0) y = (i / (double)(t.edge[j + 1] - a)) * d;     // only when it can matter
+// K8's block tables (same area): edge[32] ints | pk[2048] shorts (as K7's, see p1w_k7_tables) | deqs[256] doubles =
+// a^(1/0.75) / 2^(bits-1) (exact: the scale is a power of two) | thrt[256] doubles = (e/2)^(t^0.75)
+struct P1K8Lds { const int* edge; const unsigned short* pk; const double* deqs; const double* thrt; };
+constexpr int kK8EdgeOff = 0, kK8PkOff = 128, kK8DeqOff = 128 + 4096, kK8ThrOff = 128 + 4096 + 2048;
+static_assert(kK8ThrOff + 2048 <= kP1BlockBytes, "K8 tables");
+__device__ __forceinline__ P1K8Lds p1w_k8_lds(unsigned char* smem) {
+    unsigned char* b = smem + kWaveLdsBytes + 16;
+    return {reinterpret_cast<const int*>(b + kK8EdgeOff), reinterpret_cast<const unsigned short*>(b + kK8PkOff),
+            reinterpret_cast<const double*>(b + kK8DeqOff), reinterpret_cast<const double*>(b + kK8ThrOff)};
+}
+__device__ __forceinline__ int k7_bin_of(int s, int cls, int l);
+// phase 1 (before a block barrier): edges and the two value tables; phase 2 (after it): the bin -> (band, position) map
+__device__ __forceinline__ void p1w_k8_tables_a(unsigned char* smem, const P1Wave& pw, double inv_scale) {
+    unsigned char* b = smem + kWaveLdsBytes + 16;
+    if (threadIdx.x < 28) reinterpret_cast<int*>(b + kK8EdgeOff)[threadIdx.x] = pw.edge[threadIdx.x];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        reinterpret_cast<double*>(b + kK8DeqOff)[i] = pw.deq[i] * inv_scale;
+        reinterpret_cast<double*>(b + kK8ThrOff)[i] = pw.deq[256 + i];
     }
-    return y + t0;
+}
+__device__ __forceinline__ void p1w_k8_tables_b(unsigned char* smem, const P1Wave& pw) {
+    unsigned char* b = smem + kWaveLdsBytes + 16;
+    const int* edge = reinterpret_cast<const int*>(b + kK8EdgeOff);
+    unsigned short* pk = reinterpret_cast<unsigned short*>(b + kK8PkOff);
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) {
+        const int cls = i & 3, l = (i >> 2) & 31, s = i >> 7;
+        const int kb = k7_bin_of(s, cls, l), j = pw.band_of[kb];
+        pk[i] = (unsigned short)(j < 26 ? ((kb - edge[j]) | (j << 10)) : (31 << 10));      // band 31: {0, 0} (bins past the last band start)
+    }
 }
 __device__ __forceinline__ double p1w_quant(double x) {        // sign(x) |x|^0.75 (p1tools.py:43)
     const double a = fabs(x), r = sqrt(a);
     return copysign(r * sqrt(r), x) * (a != 0.0);
 }
-__device__ __forceinline__ double p1w_dequant(double x) { const double a = fabs(x); return copysign(a * cbrt(a), x) * (a != 0.0); }
 
 // (int) round(sign(m) |m * scale|^0.75) with m = x / div -- the per-bin quantiser of profile1.py:27-36 -- decided in
 // float32 whenever that is safe: the float32 value of |.|^0.75 carries a relative error below 1.5e-6 (two conversions,
@@ -1242,7 +1255,7 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
         for (int i = threadIdx.x; i < WaveLayout::SLOTS; i += blockDim.x) l[i] = blob[i];
     }
     const cx<T>* ltab = reinterpret_cast<const cx<T>*>(smem);
-    if constexpr (MODE == 1) p1w_tables_to_lds(smem, pw);
+    if constexpr (MODE == 1) p1w_k8_tables_a(smem, pw, 1.0 / pw.scale);
 #ifdef FRAD_HOST_EMULATION
     const int wv = threadIdx.x >> 6;
 #else
@@ -1305,30 +1318,27 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
             w[s][3] = fetch(pC[j] + o);
         }
     };
-    [[maybe_unused]] const P1Lds2 p1t = p1w_lds(smem);
-    [[maybe_unused]] double inv_scale = 1.0;
-    if constexpr (MODE == 1) inv_scale = 1.0 / pw.scale;
-    [[maybe_unused]] double* const thr = reinterpret_cast<double*>(wbuf);      // MODE 1: this wave's thresholds and ramp steps,
-    [[maybe_unused]] double* const stp = thr + 64;                             //         valid from the unit's start to its pair step
-    auto value = [&](code_t c, [[maybe_unused]] int kbin) -> T {   // stored code -> float64, NaN / Inf -> 0 (profile0.py:62-66)
-        if constexpr (MODE == 1) {
-            // profile 1: dequantise (p1tools.py:44) / 2^(bits-1), times the threshold ramp at this bin (profile1.py:71-74)
-            const int32_t qv = (int32_t)c;
-            if (qv == 0) return 0.0;
-            const int hh = (threadIdx.x >> 5) & 1;
-            const int32_t aq = qv < 0 ? -qv : qv;
-            // |q|^(1/0.75): small magnitudes (nearly all of them) from the LDS table, the rest through cbrt
-#if defined(FRAD_X_K8) && (FRAD_X_K8 & 2)
-            const double dq = (double)qv; (void)aq;
-#else
-            const double dq = (uint32_t)aq < 256u ? (qv < 0 ? -p1t.deq[aq] : p1t.deq[aq]) : p1w_dequant((double)qv);
-#endif
-#if defined(FRAD_X_K8) && (FRAD_X_K8 & 1)
-            (void)hh; return (dq * inv_scale) * thr[kbin & 31];
-#else
-            return (dq * inv_scale) * p1w_spread(p1t, thr, stp, hh, kbin);
-#endif   // scale = 2^(bits-1): the product is the quotient, exactly
-        } else
+    // MODE 1 (K8): the table-driven dequantiser.  Per bin: |q|^(4/3) / 2^(bits-1) from an LDS table (one multiply saved: the
+    // scale is a power of two), the bin's band and position inside it from the pk map (one 8-byte read per job), the band's
+    // {threshold, ramp step} as one 16-byte read, numpy's linspace arithmetic t0 + i * step (two roundings, p1tools.py:35-41),
+    // one product, the sign.  What the tables do not hold -- a band code outside [0, 256), |q| >= 256 -- marks the frame for
+    // the exact kernel behind this one (pw.redo); `big` collects the magnitudes.  With table thresholds (all >= 1, spaced by
+    // >= 2^-52) numpy's second linspace branch (a step that underflows while the end points differ) cannot be reached.
+    [[maybe_unused]] const P1K8Lds p1t = p1w_k8_lds(smem);
+    [[maybe_unused]] double* const rec = reinterpret_cast<double*>(wbuf);      // MODE 1: rec[(h * 32 + band) * 2] = threshold, [+ 1] = ramp
+                                                                               // step; valid from the unit's start to its pair step
+    [[maybe_unused]] uint32_t big = 0;
+    [[maybe_unused]] auto value_p1 = [&](uint32_t c, uint32_t en, const unsigned char* recb) -> T {
+        const int32_t qv = (int32_t)c;
+        const uint32_t aq = (uint32_t)(qv < 0 ? -qv : qv);
+        big |= aq;
+        const double dq = p1t.deqs[aq & 255u];
+        const v2d rc = *reinterpret_cast<const v2d*>(recb + ((en >> 6) & 0x3f0u));
+        const double y = (double)(int)(en & 1023u) * rc[1];
+        const double x = dq * (y + rc[0]);
+        return u2d(d2u(x) | ((u64)(c & 0x80000000u) << 32));
+    };
+    auto value = [&](code_t c) -> T {                          // stored code -> float64, NaN / Inf -> 0 (profile0.py:62-66)
         if constexpr (BITS == 32) {
             float f = u2f(wave_perm(c, psel));
 #ifdef FRAD_HOST_EMULATION
@@ -1365,6 +1375,7 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
     };
     if constexpr (MODE == 1) { if (u < ue) tq_pf = tq_fetch(u); }
     __syncthreads();                                          // tables and counter are in LDS
+    if constexpr (MODE == 1) { p1w_k8_tables_b(smem, pw); __syncthreads(); }
     for (int i = (wv * 8 + (int)(blockIdx.x & 7)) * g.cg; i > 0; --i) FRAD_WAVE_SLEEP(1);      // start stagger (g.cg x 64 cycles per step; 0 = off)
     while (u < ue) {
         lane = threadIdx.x & 63; FRAD_OPAQUE(lane);
@@ -1372,22 +1383,22 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
         const bool lane0 = (l == 0);
         const long long next = ub + wave_next_unit(ctr);
         if constexpr (!PF) load_words(u, -1);
-#if defined(FRAD_X_K8) && (FRAD_X_K8 & 4)
-        if constexpr (false) {
-#else
+        [[maybe_unused]] bool bad = false;                     // MODE 1: this lane saw something the tables do not hold
         if constexpr (MODE == 1) {
-#endif
             // thresholds of this unit's frame(s): thr[b] = (e/2)^quant(tq[b]) (profile1.py:63), ramp steps (p1tools.py:35-41)
+            big = 0;
             if (l < 27) {
                 const int32_t ti = tq_pf;
-                // small codes (all that a sane stream holds) from the LDS table; pow only if some lane's code is not one
-                thr[h * 32 + l] = (uint32_t)ti < 256u ? p1t.deq[256 + ti] : pow(2.718281828459045 / 2, p1w_quant((double)ti));
+                bad = (uint32_t)ti >= 256u;
+                rec[(h * 32 + l) * 2] = p1t.thrt[bad ? 0 : ti];
+            } else if (l == 31) {
+                rec[(h * 32 + 31) * 2] = 0.0; rec[(h * 32 + 31) * 2 + 1] = 0.0;       // bins past the last band start (pk band 31)
             }
             team_sync<64>();
             if (l < 27) {
                 double st = 0.0;
-                if (l < 26) { const int num = p1t.edge[l + 1] - p1t.edge[l]; if (num > 0) st = (thr[h * 32 + l + 1] - thr[h * 32 + l]) / (double)num; }
-                stp[h * 32 + l] = st;
+                if (l < 26) { const int num = p1t.edge[l + 1] - p1t.edge[l]; if (num > 0) st = (rec[(h * 32 + l + 1) * 2] - rec[(h * 32 + l) * 2]) / (double)num; }
+                rec[(h * 32 + l) * 2 + 1] = st;
             }
             team_sync<64>();
         }
@@ -1396,9 +1407,12 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
         {
             cx<T> zk[16], zm[16];
             cx<T> ptab[2][2];
+            [[maybe_unused]] v2u ent[2];                       // MODE 1: the job's four (band, position) entries, fetched a job ahead
+            [[maybe_unused]] const unsigned char* recb = wbuf + h * 512;
             auto ptab_load = [&](int s) {
                 ptab[s & 1][0] = ltab[WaveLayout::PW + s * 32 + l];
                 ptab[s & 1][1] = ltab[WaveLayout::PG + s * 32 + l];
+                if constexpr (MODE == 1) ent[s & 1] = reinterpret_cast<const v2u*>(p1t.pk)[32 * s + l];
             };
             auto inv_pair = [&](T xk, T xnk, T a, T b, cx<T> wk, cx<T> gk, cx<T>& rk, cx<T>& rm) {
                 const cx<T> uu = {xk, -xnk};
@@ -1414,15 +1428,24 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
                 if (s + 1 < 16) ptab_load(s + 1);
                 FRAD_FENCE();
                 // bins of the four words (see load_words): k, N - k, M - k, M + k; lane 0 of job 0 borrows 1536 and 512
-                const int kq = wave_job_k(l, s);
-                const T xa = value(w[s][0], kq), xd = value(w[s][1], (s == 0 && lane0) ? 1536 : N - kq),
-                        xb = value(w[s][2], (s == 0 && lane0) ? 512 : M - kq), xc = value(w[s][3], M + kq);
+                T xa, xd, xb, xc;
+                if constexpr (MODE == 1) {
+                    // pk classes (k7_bin_of): 0 = k, 1 = M - k, 2 = M + k, 3 = N - k; lane 0 of job 0: 0, 512, 1024, 1536
+                    const v2u e2 = ent[s & 1];
+                    xa = value_p1(w[s][0], e2[0] & 0xffffu, recb); xd = value_p1(w[s][1], e2[1] >> 16, recb);
+                    xb = value_p1(w[s][2], e2[0] >> 16, recb); xc = value_p1(w[s][3], e2[1] & 0xffffu, recb);
+                } else {
+                    xa = value(w[s][0]); xd = value(w[s][1]); xb = value(w[s][2]); xc = value(w[s][3]);
+                }
                 if (s == 0) {
                     // lane 0: k = 0 (X[N] = 0, X[M] on both sides) and, from the two borrowed words, the self-paired k = 512
                     inv_pair(xa, lane0 ? 0.0 : xd, lane0 ? xc : xb, xc, ptab[0][0], ptab[0][1], zk[0], zm[0]);
                     inv_pair(xb, xd, xb, xd, ltab[WaveLayout::TW1 + 0], ltab[WaveLayout::TW1 + 1], zsp, dump);
                 } else {
                     inv_pair(xa, xd, xb, xc, ptab[s & 1][0], ptab[s & 1][1], zk[s], zm[s]);
+                }
+                if constexpr (MODE == 1) {                     // the job's arithmetic stays in the job (the scheduling fence alone does not
+                    FRAD_PIN(zk[s].x); FRAD_PIN(zk[s].y); FRAD_PIN(zm[s].x); FRAD_PIN(zm[s].y);   //  hold pure arithmetic)
                 }
                 FRAD_FENCE();
             }
@@ -1436,7 +1459,19 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
             }
         }
         FRAD_FENCE();
-        if constexpr (MODE == 1) team_sync<64>();              // thresholds read by every lane before the planes overwrite them
+        if constexpr (MODE == 1) {
+            team_sync<64>();                                   // thresholds read by every lane before the planes overwrite them
+            bad |= big > 255u;
+            if (wave_any(bad)) {                               // rare: hand the frame(s) to the exact kernel
+                if constexpr (CC == 2) {
+                    if (lane == 0) { const int i = atomicAdd(pw.redo, 1); pw.redo[1 + i] = (int)u; }
+                } else {
+                    const bool lo = wave_any(bad && h == 0), hi = wave_any(bad && h == 1);
+                    const long long ff = 2 * u + h;
+                    if (l == 0 && (h ? hi : lo) && ff < g.n_frames) { const int i = atomicAdd(pw.redo, 1); pw.redo[1 + i] = (int)ff; }
+                }
+            }
+        }
         // ---- inverse 16-point DFTs over m; the odd half takes conj(W_32^n) --------------------------
         dft<16, true>(E);
         FRAD_FENCE();

@@ -68,6 +68,7 @@ template <typename F> void launch(dim3 grid, dim3 block, size_t lds, F&& body) {
 #define gridDim emu::g_dim
 #define FRAD_DYN_SMEM(name) unsigned char* name = emu::smem_base()
 #define FRAD_OPAQUE(x) asm volatile("" : "+r"(x))
+#define FRAD_PIN(x) ((void)(x))
 #define FRAD_GPTR(T, p) ((T*)(p))
 #define FRAD_GCPTR(T, p) ((const T*)(p))
 #define FRAD_LDS_BARRIER() __syncthreads()
@@ -104,6 +105,7 @@ inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v)
 }
 
 inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
 inline long long __double_as_longlong(double d) { long long r; std::memcpy(&r, &d, 8); return r; }
 inline double __longlong_as_double(long long v) { double r; std::memcpy(&r, &v, 8); return r; }

@@ -68,6 +68,28 @@ def test_p1_vs_oracle_sizes_and_rates(be, geom):
             assert np.max(np.abs(dec - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
 
 
+@pytest.mark.parametrize("C", [2, 1])
+def test_p1_decode_of_frames_the_tables_do_not_hold(be, C):
+    """K8 at N = 2048 is table-driven (band codes 0 .. 255, |q| < 256); anything else -- a corrupt stream's codes, an
+    extremely loud bin -- is marked by the wave kernel and decoded again by the exact kernel behind it.  Normal and
+    marked frames are mixed (odd frame count: the mono kernel's half-empty last wave)."""
+    N, F, srate = 2048, 7, 48000
+    rng = np.random.default_rng(77 + C)
+    raw = synth.to_pcm(synth.harmonic_mix(F * N, C, srate, seed=5 + C), "s16le")
+    q, tq = be.p1_analogue(raw, "s16le", F, N, C, 16, srate, 0.553)
+    q, tq = q.copy(), tq.copy()
+    tq[1, 3, C - 1] = 300                                      # beyond the threshold table
+    tq[2, 5, 0] = -5                                           # a negative code: threshold < 1 (only a damaged stream has one)
+    q[3, 17, 0] = 1000; q[3, 900, C - 1] = -70000              # beyond the |q|^(4/3) table
+    tq[5, :, :] = rng.integers(-3, 400, size=(27, C)); q[5, ::7, :] = rng.integers(-500, 500, size=q[5, ::7, :].shape)
+    tq[6, 26, 0] = 256                                         # last frame, first code past the table
+    dec = be.p1_digital(q, tq, N, C, 16, srate)
+    for f in range(F):
+        ref = fo.p1_digital_post(q[f].reshape(-1), tq[f].reshape(-1), 2, C, srate, N)
+        assert np.all(np.isfinite(ref))
+        assert np.max(np.abs(dec[f] - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref))), f"frame {f}"
+
+
 def test_p1_short_frame_is_zero_padded(be):
     """flush: the last frame is shorter than the compact size and is padded (profile1.py:19)."""
     N, C, nv = 1024, 2, 900
