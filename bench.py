@@ -149,10 +149,12 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo", rank=rank, world_size=world)
         a, b = shard_range(4096, rank, world)
-        elapsed = Timer(dist).measure(lambda: time.sleep(0.01 * (rank + 1)))
+        timer = Timer(dist)
+        elapsed = timer.measure(lambda: time.sleep(0.01 * (rank + 1)))
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "dry_run": True, "ms_per_step": round(elapsed * 1e3, 3),
+                              "rank_ms_per_step": {"min": round(min(timer.per_rank) * 1e3, 3), "max": round(max(timer.per_rank) * 1e3, 3)},
                               "clips_rank0": b - a}), flush=True)
         if dist is not None:
             dist.destroy_process_group()
@@ -305,7 +307,8 @@ def main():
         for i in range(args.steps):
             wl.step(ev_enc[i], ev_dec[i])
     # barrier + torch.cuda.synchronize() on both sides of exactly K steps, MAX over ranks (parallel.Timer)
-    elapsed = Timer(dist, torch.cuda.synchronize).measure(timed_steps)
+    timer = Timer(dist, torch.cuda.synchronize)
+    elapsed = timer.measure(timed_steps)
     assert int(wl.over.item()) == 0, "synthetic audio must not overflow float32 storage"
 
     enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_enc]))
@@ -362,6 +365,9 @@ def main():
         cd_ms = float(np.mean([a.elapsed_time(b) for a, b in cd[5:]]))
         extra["roofline_cold"] = {"encode": roof(ENC_NAME, enc_bytes, ce_ms), "decode": roof(DEC_NAME, dec_bytes, cd_ms),
                                   "note": "3 rotating buffer sets, reuse distance > 2 GB (Infinity Cache is 256 MiB)"}
+        # the HBM-honest fraction next to the pipeline one, inside the parsed roofline block: in a step the payload decode reads
+        # was written a launch earlier and partly comes from the Infinity Cache; `frac_cold` has no such help
+        r_enc["frac_cold"], r_dec["frac_cold"] = extra["roofline_cold"]["encode"]["frac"], extra["roofline_cold"]["decode"]["frac"]
         # ---- yardstick: the library's own 16 B/lane copy kernel over the encode-sized and decode-sized footprints ----
         src = wc.sets[0]["out"].view(torch.uint8).reshape(-1)
         dst = wc.sets[1]["out"].view(torch.uint8).reshape(-1)
@@ -386,6 +392,8 @@ def main():
             "metric": METRIC,
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            # every rank's own time to its local device sync, before the closing barrier: a straggler is visible here
+            "rank_ms_per_step": {"min": round(min(timer.per_rank) / args.steps * 1e3, 4), "max": round(max(timer.per_rank) / args.steps * 1e3, 4)},
             "scaling": "weak" if args.workload == "cfg2" else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("configs[1]: 10 min 48 kHz stereo s16le, profile 0, bits=32 BE, frame=2048, "

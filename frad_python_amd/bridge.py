@@ -139,7 +139,7 @@ class HipBridge:
         t = self.torch
         off = np.zeros(len(bodies) + 1, np.int64)
         np.cumsum([len(b) for b in bodies], out=off[1:])
-        flat = self._up(b"".join(bodies))
+        flat = self._up(b"".join(bodies) + bytes(8))              # the decoder reads the stream as aligned 32-bit words: tail slack (frad_hip.h)
         q, tq, status = self.core.p1_golomb_decode_batch(flat, t.from_numpy(off).to(self.device), N, C)
         return self.core.p1_digital_batch(q, tq, N, C, bits, srate).cpu().numpy()
 

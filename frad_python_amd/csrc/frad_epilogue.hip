@@ -239,6 +239,7 @@ int64_t frad_asfh_scan(const void* stream_bytes, int64_t nbytes, int64_t start, 
             if (fi.force_flush) {
                 fi.payload_off = h0 + hlen; fi.payload_bytes = 0;
                 frames[n++] = fi; pos = h0 + hlen;
+                if (n == max_frames) { *stop_reason = FRAD_SCAN_TABLE_FULL; break; }
                 continue;
             }
             fi.overlap_ratio = d[h0 + 11] ? d[h0 + 11] + 1 : 0;

@@ -528,7 +528,7 @@ int frad_rows_compact(const void* rows, int64_t row_stride, const int64_t* row_b
     if (n_rows < 0 || row_stride < 0) return FRAD_E_INVALID;
     if (!offsets) return FRAD_E_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (n_rows > 0 && (!rows || !row_bytes || (reinterpret_cast<uintptr_t>(rows) & 3) || (row_stride & 3))) return FRAD_E_INVALID;
+    if (n_rows > 0 && (!rows || !row_bytes || (reinterpret_cast<uintptr_t>(rows) & 3) || (row_stride & 3) || row_stride < 4)) return FRAD_E_INVALID;
     if (n_rows > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
     hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(GT), GT * 8, s, reinterpret_cast<const long long*>(row_bytes), (long long)n_rows, reinterpret_cast<long long*>(offsets));
     if (n_rows > 0 && out)

@@ -11,20 +11,10 @@
 
 namespace frad {
 
-// FRAD_TUNE_* experiment knobs: the environment is read ONCE per variable and process, not per launch
-inline const char* tune(const char* name) {
-    static std::mutex mu;
-    static std::map<std::string, std::string> seen;
-    static std::map<std::string, bool> have;
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = have.find(name);
-    if (it == have.end()) {
-        const char* e = std::getenv(name);
-        it = have.emplace(name, e != nullptr).first;
-        if (e) seen[name] = e;
-    }
-    return it->second ? seen[name].c_str() : nullptr;
-}
+// FRAD_TUNE_* experiment knobs: the environment is read ONCE per call site and process (a function-local
+// static per distinct use: no lock, no map on the launch path)
+inline const char* tune_env(const char* name) { const char* e = std::getenv(name); return e ? (new std::string(e))->c_str() : nullptr; }
+#define tune(name) ([]() -> const char* { static const char* const v_ = ::frad::tune_env(name); return v_; }())
 
 struct Tables { void* tw = nullptr; void* post = nullptr; void* blob = nullptr; void* blob_b = nullptr; void* blob_i = nullptr; };   // blob: LDS image of the persistent kernels
 

@@ -28,6 +28,15 @@ void go_p1_fwd_lg(int lg, const void* blob, int grid, hipStream_t s, const unsig
 }
 }  // namespace
 
+#if defined(FRAD_WAVE_STAMPS)
+extern "C" int frad_debug_wave_stamps_p1(unsigned long long* out, int reset) {      // this translation unit's copy of the counters
+    unsigned long long z[16] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_stamps), sizeof(z)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_wave_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
 // K7.  Needs whole frames (n_valid = N), 16-byte aligned PCM rows (ai), integer or float64 PCM of 2, 4 or 8 bytes.
 int launch_p1_fwd_wave(int lg, hipStream_t s, const unsigned char* pcm, int32_t* q, const Geom& g, const P1Wave& pw, int ai, unit_root_fn unit) {
     if (wave_off() || p1_wave_off() || g.N != 2048 || (g.C != 1 && g.C != 2) || !ai || g.n_valid != g.N || lg < 1) return 0;

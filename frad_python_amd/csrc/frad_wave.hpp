@@ -38,7 +38,8 @@ struct WaveLayout { static constexpr int TW1 = 0, PW = 1024, PG = 1536, SLOTS = 
 constexpr int kWaveTableBytes = WaveLayout::SLOTS * 16;
 constexpr int kWavePlaneSlots = 34 * 32;                 // one padded exchange plane: 32 rows of 32 doubles + 2 (see pslot)
 constexpr int kWaveBufBytes = 2 * kWavePlaneSlots * 8;   // 17 408 B: two planes (one per channel); the raw bytes and the payload staging alias them
-constexpr int kWaveWaves = 7;                            // 7 x 17 KiB + 32 KiB of tables = 151 of the 160 KiB
+constexpr int kWaveWaves = 7;                            // 7 x 17 KiB + 32 KiB of tables = 151 of the 160 KiB (an eighth wave -- tables cut to
+                                                         // 24 KiB -- was measured in round 3: encode 92.4 -> 90.6 us, decode 113.8 -> 116.6 us; not kept)
 constexpr int kWaveLdsBytes = kWaveTableBytes + kWaveWaves * kWaveBufBytes + 16;   // + the block's work counter
 
 // pair job (lane a in [0, 32), slot u in [0, 16)) -> its k in [0, M/2]; see the header comment and pass 2 below
@@ -91,18 +92,24 @@ __device__ __forceinline__ void tw32_apply(cx<T> (&o)[16]) {          // o[n] *=
 __device__ __forceinline__ int pslot(int r, int c) { return 34 * r + 2 * (c & 15) + (c >> 4); }
 
 // Diagnostic build only (-DFRAD_WAVE_STAMPS): per-phase shader-clock totals of wave 0 of every block, summed into
-// g_wave_stamps[phase] (cycles) and g_wave_stamps[8] (units); no stamp executes in the product build.
+// g_wave_stamps[phase] (cycles, phases 0 .. 11) and g_wave_stamps[15] (units); no stamp executes in the product build.
 #if defined(FRAD_WAVE_STAMPS) && !defined(FRAD_HOST_EMULATION)
 __device__ unsigned long long g_wave_stamps[16];
 #define FRAD_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; } while (0)
-#define FRAD_STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime(), st_units = 0
-#define FRAD_STAMP_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_wave_stamps[i_], st_acc[i_]); atomicAdd(&g_wave_stamps[8], st_units); } } while (0)
+#define FRAD_STAMP_DECL unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime(), st_units = 0
+#define FRAD_STAMP_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_wave_stamps[i_], st_acc[i_]); atomicAdd(&g_wave_stamps[15], st_units); } } while (0)
 #else
 #define FRAD_STAMP(i) ((void)0)
 #define FRAD_STAMP_DECL ((void)0)
 #define FRAD_STAMP_FLUSH ((void)0)
 #endif
 
+// section marks for tools/asm_stats.py (a comment in the assembly, no instruction)
+#ifndef FRAD_HOST_EMULATION
+#define FRAD_MARK(name) asm volatile("; FRAD_MARK " name)
+#else
+#define FRAD_MARK(name) ((void)0)
+#endif
 // work distribution inside a block: one LDS word, bumped by lane 0 of a wave and broadcast
 #ifndef FRAD_HOST_EMULATION
 #define FRAD_WAVE_LDS_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -495,10 +502,10 @@ constexpr int kK7RecOff = 16384;                      // {threshold, step} per b
 constexpr int kK7Slots = 16;                          // runs of 32 bins per band in the gather table (launch condition)
 static_assert(2 * kK7PlaneBytes <= kWaveBufBytes && kK7RecOff + 1024 <= kWaveBufBytes && 2 * 27 * kK7Slots * 8 <= 8192, "K7 LDS plan");
 
-template <int CC, typename T, typename DMA>
+template <int CC, typename T, typename DMA, typename STAMP>
 __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], const cx<T>* ltab, unsigned char* smem,
                                              unsigned char* wbuf, unsigned char* __restrict__ qout, const P1Wave& pw, const Geom& g,
-                                             long long u, int lane, DMA&& dma_next) {
+                                             long long u, int lane, DMA&& dma_next, STAMP&& stamp) {
     constexpr int M = 1024, N = 2048;
     const int h = lane >> 5, l = lane & 31;
     const bool lane0 = (l == 0);
@@ -506,6 +513,7 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
     const bool live = f < g.n_frames;
     const int c = CC == 2 ? h : 0;
     const P1K7Lds t = p1w_k7_lds(smem);
+    FRAD_MARK("k7_pair_step");
     auto sel = [&](cx<T> a, cx<T> b) { return cx<T>{lane0 ? a.x : b.x, lane0 ? a.y : b.y}; };
     // ---- the self-paired bin k = 512 (lane 0's E[8]) and lane 0's pairing --------------------------------------------
     T xs0, xs1;
@@ -558,6 +566,7 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
             FRAD_FENCE();
         }
     }
+    stamp(ic<7>{}); FRAD_MARK("k7_band_sums");
     // ---- pass A: band energies --------------------------------------------------------------------------------------
     // per-launch constants of this lane's two runs (g = 32 R + l): first band, offsets of the (at most two) band edges inside
     // the run (32 = none), slot of the run in its first band's table row
@@ -617,6 +626,7 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
     FRAD_FENCE();
     dma_next();
     FRAD_FENCE();
+    stamp(ic<8>{}); FRAD_MARK("k7_thresholds");
     // partial sums -> table [half][band][run slot]; lane b adds band b's runs
     double* tab = reinterpret_cast<double*>(wbuf) + h * (27 * kK7Slots);
 #pragma unroll
@@ -654,6 +664,7 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
         rec[2 * l + 1] = st;
     }
     team_sync<64>();
+    stamp(ic<9>{}); FRAD_MARK("k7_quantiser");
     // ---- pass B: quantiser (profile1.py:27-36), integers through the profile-0 staging rows ---------------------------
     constexpr int NB = 4, NG = 4, JPG = 4, BPC = 128, ES = CC * NB;
     int hq = h, lq = l;
@@ -862,7 +873,7 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
             // in order, so at most that many may still be in flight
             asm volatile("s_waitcnt vmcnt(%0)" :: "i"(4 * NB) : "memory");   // (profile 1: the 16 row stores follow the DMA, and one store of threshold codes before them)
 #endif
-            FRAD_STAMP(0);
+            FRAD_STAMP(0); FRAD_MARK("makhoul_convert");
             team_sync<64>();
 #ifdef FRAD_X_NOCOMPUTE
             {
@@ -948,14 +959,14 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
             tw_load(0);
             FRAD_FENCE();
         }
-        FRAD_STAMP(1);
+        FRAD_STAMP(1); FRAD_MARK("pass1");
         // ---- pass 1: DFT over j --------------------------------------------------------------------
         cx<T> e[16], o[16];
         dif32_stage<false>(z, e, o);
         dft<16, false>(e);                                     // B[2 i]     (row k2 = 2 i of the exchange)
         dft<16, false>(o);                                     // B[2 i + 1]
         FRAD_FENCE();
-        FRAD_STAMP(2);
+        FRAD_STAMP(2); FRAD_MARK("twiddle_exchange");
         // ---- twiddle W_1024^(l k2) a batch of rows at a time; real parts go straight to the exchange plane -----
         T* pl = reinterpret_cast<T*>(wbuf) + h * kWavePlaneSlots;
         T* plw = pl + 2 * (l & 15) + (l >> 4);                 // this lane's column (writer side)
@@ -1021,7 +1032,7 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every plane read has returned: the DMA may overwrite the planes
 #endif
         team_sync<64>();
-        FRAD_STAMP(3);
+        FRAD_STAMP(3); FRAD_MARK("pass2");
         FRAD_FENCE();
         if constexpr (MODE != 1) dma_in(next < ue ? next : ub);    // raw landing zone is free from here on (no branch; a wave's last DMA re-reads the
                                                                //  block's first unit, which its six neighbours hit in L2 -- never consumed)
@@ -1047,11 +1058,12 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         dft<16, false>(O);                                     // O[u] = Z[b + 32 (2 u + 1)]
         FRAD_FENCE();
         if constexpr (MODE == 1) {
-            wave_p1_tail<CC>(E, O, ltab, smem, wbuf, payload, pw, g, u, lane, [&]() { dma_in(next < ue ? next : ub); });
+            wave_p1_tail<CC>(E, O, ltab, smem, wbuf, payload, pw, g, u, lane, [&]() { dma_in(next < ue ? next : ub); },
+                             [&](auto ph) { (void)ph; FRAD_STAMP(decltype(ph)::value); });
         } else {
         ptab_load(NG - 1, 0);
         FRAD_FENCE();
-        FRAD_STAMP(4);
+        FRAD_STAMP(4); FRAD_MARK("p0_pair_pack_store");
         // ---- DCT pair step on registers; storage codes to the staging rows, rows to HBM, group by group -------
         const bool lane0 = (l == 0);
         const long long f = CC == 2 ? u : 2 * u + h;
@@ -1182,7 +1194,7 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
         }
         }                                                      // MODE 0
         team_sync<64>();
-        FRAD_STAMP(6);
+        FRAD_STAMP(6); FRAD_MARK("unit_end");
 #if defined(FRAD_WAVE_STAMPS) && !defined(FRAD_HOST_EMULATION)
         ++st_units;
 #endif

@@ -12,7 +12,6 @@ import numpy as np
 
 from . import common
 from .fourier import profiles
-from .fourier.tools import p1tools
 from .tools.asfh import ASFH
 from .backend.pcmformat import from_f64
 
@@ -109,37 +108,17 @@ class Decoder:
         payloads = [e[0] if e[0] is not None else self._data[e[1]:e[1] + e[2]] for e in entries]
         if profile == 1:
             bits = _P1_DEPTHS[depth_idx]
-            on_device = getattr(self.bridge, "p1_decode_bodies", None)
-            if on_device is not None:
-                # inflate on the host (profile1.py:59), Golomb decode + dequantise + IDCT on the device
-                def inflate(frad):
-                    try:
-                        return zlib.decompress(frad, wbits=-15)
-                    except Exception:
-                        return None                                  # profile1.py:59-60 -> a frame of zeros
-                from .encoder import _map_zlib
-                bodies = _map_zlib(inflate, payloads)              # runs of frames per pool task
-                bad = [i for i, b in enumerate(bodies) if b is None]
-                bodies = [b if b is not None else b"" for b in bodies]
-                pcm = on_device(bodies, fsize, channels, bits, srate)
-                for i in bad:
-                    pcm[i] = 0.0
-                return self._finish_run(pcm, key)
-            qs = np.zeros((len(payloads), fsize * channels), np.int32)
-            ts = np.zeros((len(payloads), 27 * channels), np.int32)
-            bad = []
-            for i, frad in enumerate(payloads):
+            # inflate on the host (profile1.py:59); Golomb decode + dequantise + IDCT behind the bridge (on the device)
+            def inflate(frad):
                 try:
-                    raw = zlib.decompress(frad, wbits=-15)
+                    return zlib.decompress(frad, wbits=-15)
                 except Exception:
-                    bad.append(i)                                   # profile1.py:59-60 -> a frame of zeros
-                    continue
-                tl = struct.unpack(">I", raw[:4])[0]
-                t = p1tools.exp_golomb_rice_decode(raw[4:4 + tl])[:27 * channels]
-                q = p1tools.exp_golomb_rice_decode(raw[4 + tl:])[:fsize * channels]
-                lim = np.iinfo(np.int32)                          # (only a corrupt stream holds values beyond int32: saturate, as the device coder does)
-                ts[i, :t.size], qs[i, :q.size] = np.clip(t, lim.min, lim.max), np.clip(q, lim.min, lim.max)
-            pcm = self.bridge.p1_decode(qs.reshape(-1, fsize, channels), ts.reshape(-1, 27, channels), fsize, channels, bits, srate)
+                    return None                                      # profile1.py:59-60 -> a frame of zeros
+            from .encoder import _map_zlib
+            bodies = _map_zlib(inflate, payloads)                  # runs of frames per pool task
+            bad = [i for i, b in enumerate(bodies) if b is None]
+            bodies = [b if b is not None else b"" for b in bodies]
+            pcm = self.bridge.p1_decode_bodies(bodies, fsize, channels, bits, srate)
             for i in bad:
                 pcm[i] = 0.0
         else:

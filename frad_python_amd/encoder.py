@@ -13,7 +13,6 @@ import numpy as np
 from .backend.pcmformat import ff_format_to_numpy_type
 from .fourier import AVAILABLE, BIT_DEPTHS, SEGMAX, profiles
 from .fourier.profiles import compact
-from .fourier.tools import p1tools
 from .tools.asfh import ASFH
 
 _LOSSLESS_DEPTHS = (12, 16, 24, 32, 48, 64)
@@ -88,12 +87,6 @@ class Encoder:
         co = zlib.compressobj(zlib.Z_DEFAULT_COMPRESSION, zlib.DEFLATED, -15)     # profile1.py:50 wbits=-15
         return co.compress(body) + co.flush()
 
-    def _p1_pack(self, q: np.ndarray, tq: np.ndarray) -> bytes:
-        """host form of the entropy stage, for bridges without a device coder (the CPU-only tests' bridge)"""
-        tg = p1tools.exp_golomb_rice_encode(tq)
-        fg = p1tools.exp_golomb_rice_encode(q)
-        return self._deflate(struct.pack(">I", len(tg)) + tg + fg)
-
     def _encode_frames(self, pcm: bytes, n_frames: int, n_eff: int, hop: int, n_valid: int) -> bytes:
         """n_frames frames of n_eff sample-frames, frame i starting i*hop sample-frames into `pcm`."""
         prof, C = self.asfh.profile, self.channels
@@ -101,18 +94,11 @@ class Encoder:
         if prof == 1:
             bits = self.bit_depth if self.bit_depth in _P1_DEPTHS else 16
             N = compact.get_samples_min_ge(n_eff)
-            on_device = getattr(self.bridge, "p1_encode_bodies", None)
-            if on_device is not None:
-                # quantiser and Exp-Golomb-Rice coder on the device; the host only deflates (profile1.py:50) and frames
-                bodies = on_device(pcm, self.pcm_format_name, n_frames, N, C, bits, compact.get_valid_srate(self.srate),
-                                   self.loss_level, hop, n_valid)
-                for frad in _map_zlib(self._deflate, bodies):
-                    out.append(self._emit(frad, _P1_DEPTHS.index(bits), n_valid))
-                return b"".join(out)
-            q, tq = self.bridge.p1_encode(pcm, self.pcm_format_name, n_frames, N, C, bits, compact.get_valid_srate(self.srate),
-                                          self.loss_level, hop, n_valid)
-            for i in range(n_frames):
-                out.append(self._emit(self._p1_pack(q[i].reshape(-1), tq[i].reshape(-1)), _P1_DEPTHS.index(bits), n_valid))
+            # quantiser and Exp-Golomb-Rice coder behind the bridge (on the device); the host only deflates (profile1.py:50) and frames
+            bodies = self.bridge.p1_encode_bodies(pcm, self.pcm_format_name, n_frames, N, C, bits, compact.get_valid_srate(self.srate),
+                                                  self.loss_level, hop, n_valid)
+            for frad in _map_zlib(self._deflate, bodies):
+                out.append(self._emit(frad, _P1_DEPTHS.index(bits), n_valid))
         else:
             bits = self.bit_depth if self.bit_depth in _LOSSLESS_DEPTHS else 16
             whole = getattr(self.bridge, "lossless_encode_stream", None)

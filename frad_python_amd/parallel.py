@@ -34,16 +34,26 @@ class Timer:
         self.sync()
 
     def measure(self, fn) -> float:
+        """Seconds for fn() on the slowest rank.  `self.per_rank` afterwards holds every rank's own time to its local device
+        sync (before the closing barrier), so that a straggler shows up in rank 0's report."""
         import torch
         self.fence()
         t0 = time.perf_counter()
         fn()
+        self.sync()
+        local = time.perf_counter() - t0                      # this rank's work, not yet waiting for the others
         self.fence()
         dt = time.perf_counter() - t0
+        self.per_rank = [local]
         if self.dist is not None and self.dist.is_initialized():
+            nccl = self.dist.get_backend() == "nccl"
             t = torch.tensor([dt], dtype=torch.float64)
-            if self.dist.get_backend() == "nccl":
-                t = t.cuda()
+            mine = torch.tensor([local], dtype=torch.float64)
+            if nccl:
+                t, mine = t.cuda(), mine.cuda()
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            every = [torch.zeros_like(mine) for _ in range(self.dist.get_world_size())]
+            self.dist.all_gather(every, mine)
             dt = float(t.item())
+            self.per_rank = [float(x.item()) for x in every]
         return dt

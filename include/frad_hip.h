@@ -85,10 +85,6 @@ int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
                      int64_t frame_stride, int32_t bits, uint32_t flags,
                      void* payload, int64_t payload_stride, double* absmax, void* stream);
 
-/* The overflow test of profile0.py:24-26 over a batch, on the device: *flag |= 1 if any absmax[i] is
- * greater than the largest finite value of the `bits` storage float (NaN never is, like numpy's
- * comparison).  `flag` is a device int32 the caller zeroes once and reads when it needs the answer
- * (sticky across calls), so a steady stream of batches needs no host round trip per batch.        */
 /* frad_p0_analogue with the reference's per-frame overflow test (profile0.py:24-26) applied in the same pass:
  * *overflow_flag is set to 1 when any frame's max|X| exceeds the storage float's largest finite value (NaN does not
  * count, as in the reference), and left alone otherwise.  The N = 2048 wave kernels test as they go; every other
@@ -96,6 +92,10 @@ int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
 int frad_p0_analogue_checked(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C,
                              int64_t frame_stride, int32_t bits, uint32_t flags, void* payload, int64_t payload_stride,
                              double* absmax, int32_t* overflow_flag, void* stream);
+/* The overflow test of profile0.py:24-26 over a batch, on the device: *flag |= 1 if any absmax[i] is
+ * greater than the largest finite value of the `bits` storage float (NaN never is, like numpy's
+ * comparison).  `flag` is a device int32 the caller zeroes once and reads when it needs the answer
+ * (sticky across calls), so a steady stream of batches needs no host round trip per batch.        */
 int frad_p0_overflow_scan(const double* absmax, int64_t n_frames, int32_t bits, int32_t* flag, void* stream);
 
 /* frad_p0_digital == fourier.profile0.digital (profile0.py:46-69): unpack, NaN/Inf -> 0, inverse
@@ -119,7 +119,8 @@ int frad_p4_digital(const void* payload, int64_t payload_stride, int64_t n_frame
  * encoder overlaps, encoder.py:35-51) and is zero-padded to N (profile1.py:19).
  *   q   int32 [n_frames, N, C]  bin-major / channel-minor   (freqs_flat, profile1.py:34-36)
  *   tq  int32 [n_frames, 27, C] band-major / channel-minor  (thres_flat, profile1.py:38-40)
- * Exp-Golomb + deflate (profile1.py:43-50) stay on the host.                                       */
+ * The Exp-Golomb-Rice stage that follows (profile1.py:43-45) is frad_p1_golomb_encode below; zlib's deflate
+ * (profile1.py:50) stays on the host.                                                                  */
 int frad_p1_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C,
                      int64_t frame_stride, int32_t n_valid, int32_t bits, int32_t srate, double loss_level,
                      uint32_t flags, int32_t* q, int32_t* tq, void* stream);
@@ -146,13 +147,18 @@ int frad_p1_overlap_add(const double* frames, int64_t n_frames, int32_t N, int32
  *
  * frad_rows_compact: offsets[0] = 0, offsets[i+1] = offsets[i] + row_bytes[i] (n_rows + 1 entries), and, when `out`
  * is not NULL, row i's first row_bytes[i] bytes copied to out + offsets[i] -- the batch then goes to the host as ONE
- * copy of exactly the bytes deflate needs.
+ * copy of exactly the bytes deflate needs.  The gather reads a row as aligned 32-bit words: every row needs
+ * row_bytes[i] + 4 <= row_stride (frad_p1_golomb_bound includes that slack); rows that violate it are refused
+ * with FRAD_E_INVALID only when row_stride < 4 -- the per-row lengths live on the device.
  *
  * frad_p1_golomb_decode == the two exp_golomb_rice_decode calls of profile1.py:59-64 (p1tools.py:62-74) plus untrim
  * (profile1.py:12-13): frame i's inflated body is bodies[offsets[i] .. offsets[i+1]); q [n_frames, N, C] and
  * tq [n_frames, 27, C] receive the decoded integers, zero-filled where the stream ends early and cut at N*C / 27*C
  * values; values outside int32 (only a corrupt stream has them) saturate.  status[i] (may be NULL) = 1 when the body
- * is shorter than its length word.                                                                       */
+ * is shorter than its length word.  `bodies` needs 8 readable bytes after offsets[n_frames] (the streams are read as
+ * aligned 32-bit words) and must not be NULL even when every body is empty.
+ * Deviation on damaged streams only: missing band codes are zero-filled as INTEGERS (threshold (e/2)^0 = 1), where
+ * the reference pads the dequantised thresholds with 0.0 (profile1.py:63-65) and thereby silences the affected bins. */
 size_t frad_p1_golomb_bound(int32_t N, int32_t C);
 int frad_p1_golomb_encode(const int32_t* q, const int32_t* tq, int64_t n_frames, int32_t N, int32_t C,
                           void* bodies, int64_t body_stride, int64_t* body_bytes, void* stream);
@@ -189,7 +195,9 @@ int frad_p1_digital_pcm(const int32_t* q, const int32_t* tq, int64_t n_frames, i
  * FRM_SIGN and parses every header as ASFH.read does (tools/asfh.py:98-134; the search as decoder.py:82-90), filling
  * frames[0 .. return value).  Stops at the first header or payload that is not completely inside the buffer, at
  * max_frames, or at the end; *next_pos = where the next call (with more data appended) must resume, *stop_reason says
- * why.  Force-flush headers are table rows with force_flush = 1 and no payload.  Returns the row count or FRAD_E_INVALID. */
+ * why.  Force-flush headers are table rows with force_flush = 1 and no payload.  A compact header whose sample-rate
+ * index is not in the table (>= 12; the reference raises) is reported with srate = 0.  Returns the row count or
+ * FRAD_E_INVALID. */
 typedef struct frad_frame_info {
     int64_t header_off, payload_off, payload_bytes;
     int32_t profile, ecc, little_endian, depth_idx, channels, srate, fsize, overlap_ratio, ecc_dsize, ecc_codesize, force_flush;

@@ -343,6 +343,31 @@ class OracleBridge:
             q[f] = a.reshape(N, C); tq[f] = b.reshape(27, C)
         return q, tq
 
+    def p1_encode_bodies(self, pcm, fmt, n_frames, N, C, bits, srate, loss_level, hop, n_valid, raw_be_ints=True):
+        """pre-deflate frame bodies (profile1.py:43-45) with the oracle's Exp-Golomb-Rice coder"""
+        import struct
+        fo = self.fo
+        q, tq = self.p1_encode(pcm, fmt, n_frames, N, C, bits, srate, loss_level, hop, n_valid, raw_be_ints)
+        out = []
+        for f in range(n_frames):
+            tg, fg = fo.golomb_encode(tq[f].reshape(-1)), fo.golomb_encode(q[f].reshape(-1))
+            out.append(struct.pack(">I", len(tg)) + tg + fg)
+        return out
+
+    def p1_decode_bodies(self, bodies, N, C, bits, srate):
+        """inflated frame bodies -> PCM with the oracle's decoder (profile1.py:59-77; values beyond int32 saturate as on the device)"""
+        import struct
+        fo = self.fo
+        qs = np.zeros((len(bodies), N * C), np.int32); ts = np.zeros((len(bodies), 27 * C), np.int32)
+        lim = np.iinfo(np.int32)
+        for i, raw in enumerate(bodies):
+            if len(raw) < 4:
+                continue
+            tl = struct.unpack(">I", raw[:4])[0]
+            t = fo.golomb_decode(raw[4:4 + tl])[:27 * C]; q = fo.golomb_decode(raw[4 + tl:])[:N * C]
+            ts[i, :t.size], qs[i, :q.size] = np.clip(t, lim.min, lim.max), np.clip(q, lim.min, lim.max)
+        return self.p1_decode(qs.reshape(-1, N, C), ts.reshape(-1, 27, C), N, C, bits, srate)
+
     def p1_decode(self, q, tq, N, C, bits, srate):
         fo = self.fo
         return np.stack([fo.p1_digital_post(q[i].reshape(-1), tq[i].reshape(-1), fo.P1_DEPTHS.index(bits), C, srate, N)

@@ -80,6 +80,20 @@ def main():
                 if tgt in labels and labels[tgt] <= idx and idx - labels[tgt] > best[0]:
                     best = (idx - labels[tgt], labels[tgt], idx)
         print(f"{d}: {len(ins)} instructions {total}")
+        # sections between "; FRAD_MARK name" comments (inline-asm marks of the kernel source), in program order
+        marks = []
+        n = 0
+        for ln in body:
+            st = ln.strip()
+            m = re.search(r"FRAD_MARK (\w+)", st)
+            if m and not st.startswith("."):
+                marks.append((m.group(1), n)); continue
+            if st and not st.startswith((";", ".", "//")) and not re.match(r"^(\.?\w+):", st):
+                n += 1
+        for (name, a), (_, b) in zip(marks, marks[1:] + [("end", len(ins))]):
+            sm = mix(ins[a:b])
+            slots = sm.get("v_f64", 0) + sm.get("v_other", 0) + 4 * sm.get("trans", 0)
+            print(f"    [{name:>20}] {b - a:5d} instr, VALU slots {slots:5d}  {sm}")
         if best[0]:
             lm = mix(ins[best[1]:best[2] + 1])
             issue = lm.get("v_f64", 0) + lm.get("v_other", 0) + 4 * lm.get("trans", 0)
