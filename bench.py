@@ -198,9 +198,10 @@ def main():
     lib.plan_prepare(FSIZE, False)
 
     class Workload:
-        """cfg2: one 10-minute clip per rank (n_clips = 1).  cfg3: this rank's share of 4096 one-second clips; the 23
-        full frames of every clip are gathered into one batch (a strided device copy inside the step -- the batched
-        API takes one frame stride), the 896-sample tails into another (Bluestein kernels)."""
+        """cfg2: one 10-minute clip per rank (n_clips = 1).  cfg3: this rank's share of 4096 one-second clips, resident as
+        [clips, 48000, C] and consumed / produced IN PLACE (frad_p0_analogue_clips / frad_p0_digital_clips: no gathered
+        copies): the 23 full frames of every clip are one batch on the main stream, the 896-sample tails (Bluestein
+        kernels) another on the side stream, which never joins inside the timed region."""
 
         def __init__(self, seed, sets=1):
             if args.workload == "cfg2":
@@ -227,14 +228,15 @@ def main():
                     d["clips"] = base.repeat((self.n_clips + 7) // 8, 1, 1)[:self.n_clips].contiguous()
                 d["pay"] = torch.empty((self.n_full, nb), dtype=torch.uint8, device=dev)
                 d["absmax_all"] = torch.empty(self.n_full + self.n_tail, dtype=torch.float64, device=dev)
-                d["out"] = torch.empty((self.n_full, FSIZE, CHANNELS), dtype=torch.float64, device=dev)
-                if self.gather:
-                    d["body"] = torch.empty((self.n_clips, self.full_per_clip * FSIZE, CHANNELS), dtype=torch.int16, device=dev)
-                    d["tails"] = torch.empty((self.n_clips, self.tail, CHANNELS), dtype=torch.int16, device=dev)
+                if self.gather:                               # decoded clips, whole: full frames and tails land in place
+                    d["out_clips"] = torch.empty((self.n_clips, self.clip_len, CHANNELS), dtype=torch.float64, device=dev)
+                else:
+                    d["out"] = torch.empty((self.n_full, FSIZE, CHANNELS), dtype=torch.float64, device=dev)
                 if self.tail:
                     nbt = lib.payload_bytes(self.tail, CHANNELS, BITS)
                     d["pay_t"] = torch.empty((self.n_tail, nbt), dtype=torch.uint8, device=dev)
-                    d["out_t"] = torch.empty((self.n_tail, self.tail, CHANNELS), dtype=torch.float64, device=dev)
+                    if not self.gather:
+                        d["out_t"] = torch.empty((self.n_tail, self.tail, CHANNELS), dtype=torch.float64, device=dev)
                 self.sets.append(d)
             self.cur = self.sets[0]
             self.over = torch.zeros((), dtype=torch.int32, device=dev)
@@ -249,36 +251,38 @@ def main():
 
         def _tails(self, d):
             am = d["absmax_all"][self.n_full:]
-            src = d["tails"] if self.gather else d["clips"][0, self.full_per_clip * FSIZE:]
-            core.analogue_batch(0, src, "s16le", self.n_tail, self.tail, CHANNELS, BITS, False, check_overflow=False,
+            first = self.full_per_clip * FSIZE
+            if self.gather:                                   # every clip's last, short frame: read and written inside the clips
+                core.analogue_clips(d["clips"], "s16le", self.tail, BITS, False, first=first, out=d["pay_t"], absmax=am, overflow_flag=self.over)
+                core.digital_clips(d["pay_t"], d["out_clips"], self.tail, BITS, False, first=first)
+                return
+            core.analogue_batch(0, d["clips"][0, first:], "s16le", self.n_tail, self.tail, CHANNELS, BITS, False, check_overflow=False,
                                 out=d["pay_t"], absmax=am, overflow_flag=self.over)
             core.digital_batch(0, d["pay_t"], self.n_tail, self.tail, CHANNELS, BITS, False, out=d["out_t"])
 
         def encode(self, ev=None):
             d = self.cur
-            if self.gather:                                   # cfg3: full frames and tails of every clip into their batches
-                d["body"].copy_(d["clips"][:, :self.full_per_clip * FSIZE])
-                d["tails"].copy_(d["clips"][:, self.full_per_clip * FSIZE:])
-                src = d["body"]
-            else:
-                src = d["clips"]
             if ev: ev[0].record()
             # (the reference's per-frame overflow test, profile0.py:24-26, rides along: frad_p0_analogue_checked sets the
             #  sticky device flag; the host reads it once, after the timed region)
-            core.analogue_batch(0, src, "s16le", self.n_full, FSIZE, CHANNELS, BITS, False, check_overflow=False,
-                                out=d["pay"], absmax=d["absmax_all"][:self.n_full], overflow_flag=self.over)
+            if self.gather:
+                core.analogue_clips(d["clips"], "s16le", FSIZE, BITS, False, out=d["pay"], absmax=d["absmax_all"][:self.n_full],
+                                    overflow_flag=self.over)
+            else:
+                core.analogue_batch(0, d["clips"], "s16le", self.n_full, FSIZE, CHANNELS, BITS, False, check_overflow=False,
+                                    out=d["pay"], absmax=d["absmax_all"][:self.n_full], overflow_flag=self.over)
             if ev: ev[1].record()
             if self.tail:
-                if self.gather:
-                    self._tails(d)                            # 512 tail frames: a real batch, same stream
-                else:
-                    with torch.cuda.stream(self.side):        # one tail frame: fills CUs as the resident kernels' blocks retire
-                        self._tails(d)
+                with torch.cuda.stream(self.side):            # the tail frames fill CUs as the resident kernels' blocks retire
+                    self._tails(d)
 
         def decode(self, ev=None):
             d = self.cur
             if ev: ev[0].record()
-            core.digital_batch(0, d["pay"], self.n_full, FSIZE, CHANNELS, BITS, False, out=d["out"])
+            if self.gather:
+                core.digital_clips(d["pay"], d["out_clips"], FSIZE, BITS, False)
+            else:
+                core.digital_batch(0, d["pay"], self.n_full, FSIZE, CHANNELS, BITS, False, out=d["out"])
             if ev: ev[1].record()
 
         def step(self, ev_e=None, ev_d=None):

@@ -31,6 +31,9 @@ SYMBOLS = {
                                          c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "frad_p0_overflow_scan": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "frad_p0_digital": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_uint32, c_void_p, c_void_p]),
+    "frad_p0_analogue_clips": (c_int, [c_void_p, c_int32, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_uint32,
+                                       c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "frad_p0_digital_clips": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_uint32, c_void_p, c_int64, c_void_p]),
     "frad_p4_analogue": (c_int, [c_void_p, c_int32, c_int64, c_int32, c_int32, c_int64, c_int32, c_uint32,
                                  c_void_p, c_int64, c_void_p, c_void_p]),
     "frad_p4_digital": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_uint32, c_void_p, c_void_p]),
@@ -115,6 +118,13 @@ class FradLib:
 
     def p0_digital(self, payload, payload_stride, n_frames, N, C, bits, flags, out, stream=0):
         self._check(self.dll.frad_p0_digital(payload, payload_stride, n_frames, N, C, bits, flags, out, stream))
+
+    def p0_analogue_clips(self, pcm, dtype, n_clips, clip_stride, frames_per_clip, N, C, bits, flags, payload, payload_stride, absmax, flag, stream=0):
+        self._check(self.dll.frad_p0_analogue_clips(pcm, dtype, n_clips, clip_stride, frames_per_clip, N, C, bits, flags, payload,
+                                                     payload_stride, absmax, flag, stream))
+
+    def p0_digital_clips(self, payload, payload_stride, n_clips, frames_per_clip, N, C, bits, flags, out, out_clip_stride, stream=0):
+        self._check(self.dll.frad_p0_digital_clips(payload, payload_stride, n_clips, frames_per_clip, N, C, bits, flags, out, out_clip_stride, stream))
 
     def p4_analogue(self, pcm, dtype, n_frames, N, C, frame_stride, bits, flags, payload, payload_stride, absmax, stream=0):
         self._check(self.dll.frad_p4_analogue(pcm, dtype, n_frames, N, C, frame_stride, bits, flags, payload,

@@ -134,6 +134,61 @@ def analogue_batch(profile: int, pcm: torch.Tensor, pcm_format: str, n_frames: i
     return EncodedBatch(out, nbytes, bits, absmax, escalated)
 
 
+def analogue_clips(clips: torch.Tensor, pcm_format: str, N: int, bits: int, little_endian: bool = False, *,
+                   first: int = 0, frames_per_clip: int | None = None, raw_be_ints: bool = True,
+                   out: torch.Tensor | None = None, absmax: torch.Tensor | None = None,
+                   overflow_flag: torch.Tensor | None = None) -> EncodedBatch:
+    """Profile 0 ``analogue`` over a resident batch of equally long clips ``[n_clips, clip_len, C]``, consumed in place
+    (frad_p0_analogue_clips; the reference cuts every clip into frames on its own, encoder.py:72-93): ``frames_per_clip``
+    frames of N sample-frames per clip, the first one ``first`` sample-frames into the clip (default: as many whole
+    frames as fit behind ``first``).  A clip's shorter last frame is a second call with its own N and ``first``.
+    Payload row ``c * frames_per_clip + i`` is frame i of clip c.  The overflow test is the device flag only."""
+    _require_cuda(clips, "clips")
+    if clips.dim() != 3:
+        raise ValueError("clips must be [n_clips, clip_len, C]")
+    if bits not in DEPTHS:
+        bits = 16
+    lib = _lib.load()
+    code = pcm_dtype_code(pcm_format)
+    n_clips, clip_len, C = clips.shape
+    if clips.element_size() != itemsize_of(code):
+        raise ValueError("clips' element size does not match pcm_format")
+    fpc = (clip_len - first) // N if frames_per_clip is None else frames_per_clip
+    if fpc < 1 or first < 0 or first + fpc * N > clip_len:
+        raise ValueError("the frames do not fit the clip")
+    n_frames = n_clips * fpc
+    nbytes = lib.payload_bytes(N, C, bits)
+    if out is None:
+        out = torch.empty((n_frames, _align16(nbytes)), dtype=torch.uint8, device=clips.device)
+    if absmax is None:
+        absmax = torch.empty(n_frames, dtype=torch.float64, device=clips.device)
+    flags = (int(little_endian) * _lib.FRAD_LITTLE_ENDIAN) | (int(raw_be_ints) * _lib.FRAD_RAW_BE_INTS)
+    with torch.cuda.device(clips.device):
+        lib.p0_analogue_clips(clips.data_ptr() + first * C * clips.element_size(), code, n_clips, clip_len, fpc, N, C, bits, flags,
+                              out.data_ptr(), out.stride(0), absmax.data_ptr(),
+                              overflow_flag.data_ptr() if overflow_flag is not None else 0, _stream_ptr())
+    return EncodedBatch(out, nbytes, bits, absmax, {})
+
+
+def digital_clips(payload: torch.Tensor, out: torch.Tensor, N: int, bits: int, little_endian: bool = False, *,
+                  first: int = 0, frames_per_clip: int | None = None) -> torch.Tensor:
+    """Profile 0 ``digital`` of a clip batch straight into ``out`` = float64 ``[n_clips, clip_len, C]`` (frad_p0_digital_clips):
+    payload row ``c * frames_per_clip + i`` lands at ``out[c, first + i*N : first + (i+1)*N]``."""
+    _require_cuda(payload, "payload"); _require_cuda(out, "out")
+    if out.dim() != 3 or out.dtype != torch.float64:
+        raise ValueError("out must be float64 [n_clips, clip_len, C]")
+    lib = _lib.load()
+    n_clips, clip_len, C = out.shape
+    fpc = (clip_len - first) // N if frames_per_clip is None else frames_per_clip
+    if fpc < 1 or first < 0 or first + fpc * N > clip_len or payload.shape[0] < n_clips * fpc:
+        raise ValueError("the frames do not fit the clip / the payload batch")
+    flags = int(little_endian) * _lib.FRAD_LITTLE_ENDIAN
+    with torch.cuda.device(out.device):
+        lib.p0_digital_clips(payload.data_ptr(), payload.stride(0), n_clips, fpc, N, C, bits, flags,
+                             out.data_ptr() + first * C * 8, clip_len, _stream_ptr())
+    return out
+
+
 def overflow_scan(absmax: torch.Tensor, bits: int, flag: torch.Tensor) -> None:
     """``flag |= any(absmax > FLOAT_MAX[bits])`` in one launch (profile0.py:24-26 over a batch).
 

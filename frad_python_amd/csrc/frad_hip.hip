@@ -215,6 +215,10 @@ Geom make_geom(long long n_frames, int N, int C, long long frame_stride, long lo
     return g;
 }
 
+int p0_analogue_impl(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C, int64_t frame_stride,
+                     int32_t bits, uint32_t flags, void* payload, int64_t payload_stride, double* absmax,
+                     int32_t* overflow_flag, void* stream, int fpc, long long clip_stride);
+
 bool input_aligned(const void* pcm, long long frame_stride, int N, int C, int lg) {
     return aligned16(pcm) && (((frame_stride * C) << lg) % 16 == 0) && ((((long long)N * C) << lg) % 16 == 0);
 }
@@ -362,6 +366,27 @@ int frad_p0_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
 int frad_p0_analogue_checked(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C, int64_t frame_stride,
                              int32_t bits, uint32_t flags, void* payload, int64_t payload_stride, double* absmax,
                              int32_t* overflow_flag, void* stream) {
+    return p0_analogue_impl(pcm, pcm_dtype, n_frames, N, C, frame_stride, bits, flags, payload, payload_stride, absmax, overflow_flag, stream, 0, 0);
+}
+
+int frad_p0_analogue_clips(const void* pcm, int32_t pcm_dtype, int64_t n_clips, int64_t clip_stride, int32_t frames_per_clip,
+                           int32_t N, int32_t C, int32_t bits, uint32_t flags, void* payload, int64_t payload_stride,
+                           double* absmax, int32_t* overflow_flag, void* stream) {
+    if (n_clips < 0 || frames_per_clip < 1 || N < 1 || clip_stride < (int64_t)frames_per_clip * N) return FRAD_E_INVALID;
+    if (n_clips > 0x7fffffffLL / frames_per_clip) return FRAD_E_UNSUPPORTED;
+    return p0_analogue_impl(pcm, pcm_dtype, n_clips * frames_per_clip, N, C, N, bits, flags, payload, payload_stride, absmax, overflow_flag,
+                            stream, frames_per_clip, clip_stride);
+}
+
+}  // extern "C"
+namespace {
+
+// frames of the clips gathered into / scattered from a dense stream-ordered scratch (the kernels without clip addressing)
+struct StreamScratch { hipStream_t s; void* p = nullptr; ~StreamScratch() { if (p) (void)hipFreeAsync(p, s); } };
+
+int p0_analogue_impl(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32_t N, int32_t C, int64_t frame_stride,
+                     int32_t bits, uint32_t flags, void* payload, int64_t payload_stride, double* absmax,
+                     int32_t* overflow_flag, void* stream, int fpc, long long clip_stride) {
     int rc = check_common(pcm, payload, n_frames, N, C, bits);
     if (rc == FRAD_OK && overflow_flag != nullptr && absmax == nullptr && n_frames > 0) return FRAD_E_INVALID;      // the test reads the per-frame maxima
     if (rc != FRAD_OK) return rc;
@@ -372,7 +397,8 @@ int frad_p0_analogue_checked(const void* pcm, int32_t pcm_dtype, int64_t n_frame
     const int lg = (pcm_dtype >> 1) & 3;
     const bool f32 = (pcm_dtype >> 3) == 2 && lg <= 2;
     Geom g = make_geom(n_frames, N, C, frame_stride, payload_stride, bits, flags, pcm_dtype);
-    const int ai = input_aligned(pcm, frame_stride, N, C, lg) ? 1 : 0;
+    g.fpc = fpc; g.clip_stride = clip_stride;
+    const int ai = (input_aligned(pcm, frame_stride, N, C, lg) && (fpc == 0 || ((clip_stride * C) << lg) % 16 == 0)) ? 1 : 0;
     const int ao = (aligned16(payload) && payload_stride % 16 == 0) ? 1 : 0;
     const unsigned char* in = static_cast<const unsigned char*>(pcm);
     unsigned char* out = static_cast<unsigned char*>(payload);
@@ -380,6 +406,15 @@ int frad_p0_analogue_checked(const void* pcm, int32_t pcm_dtype, int64_t n_frame
         Geom gw = g;                                          // the wave kernels apply the overflow test themselves
         gw.ovf_flag = overflow_flag; gw.ovf_limit = storage_float_max(bits);
         if (launch_p0_fwd_wave(lg, s, in, out, absmax, gw, ai, ao, unit_neg)) { HIPCHK(hipGetLastError()); return FRAD_OK; }
+    }
+    if (fpc > 0 && (f32 || fast_cfg(N, C, f32).ok)) {
+        // clips through a kernel without clip addressing: the clips' frame regions are gathered into a dense scratch first
+        // (one strided device copy), then the flat batch runs on it
+        const size_t row = ((size_t)fpc * N * C) << lg;
+        StreamScratch ws{s};
+        if (hipMallocAsync(&ws.p, row * (size_t)(n_frames / fpc), s) != hipSuccess) return FRAD_E_NOMEM;
+        HIPCHK(hipMemcpy2DAsync(ws.p, row, pcm, ((size_t)clip_stride * C) << lg, row, (size_t)(n_frames / fpc), hipMemcpyDeviceToDevice, s));
+        return p0_analogue_impl(ws.p, pcm_dtype, n_frames, N, C, frame_stride, bits, flags, payload, payload_stride, absmax, overflow_flag, stream, 0, 0);
     }
     // every other kernel: the batch form of the test as a second launch on the same stream
     const int rc_all = [&]() -> int {
@@ -415,6 +450,13 @@ int frad_p0_analogue_checked(const void* pcm, int32_t pcm_dtype, int64_t n_frame
             if (r < 0) { if (r == FRAD_E_HIP) g_last_hip = blue_last_hip_error(); return r; }
             if (r == 1) { HIPCHK(hipGetLastError()); return FRAD_OK; }
         }
+        if (fpc > 0) {                                       // (Bluestein did not take it) gather the clips, then the flat batch
+            const size_t row = ((size_t)fpc * N * C) << lg;
+            StreamScratch ws{s};
+            if (hipMallocAsync(&ws.p, row * (size_t)(n_frames / fpc), s) != hipSuccess) return FRAD_E_NOMEM;
+            HIPCHK(hipMemcpy2DAsync(ws.p, row, pcm, ((size_t)clip_stride * C) << lg, row, (size_t)(n_frames / fpc), hipMemcpyDeviceToDevice, s));
+            return p0_analogue_impl(ws.p, pcm_dtype, n_frames, N, C, frame_stride, bits, flags, payload, payload_stride, absmax, nullptr, stream, 0, 0);
+        }
         const size_t per_frame = 2 * (size_t)N * C * (f32 ? 4 : 8);
         if (per_frame > (size_t)kLdsBytes) {                 // wider than a CU's LDS: HBM workspaces (frad_global.hip)
             const int r = global_p0_analogue(in, out, absmax, g, flags, s);
@@ -444,18 +486,50 @@ int frad_p0_analogue_checked(const void* pcm, int32_t pcm_dtype, int64_t n_frame
     return FRAD_OK;
 }
 
+int p0_digital_impl(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C, int32_t bits,
+                    uint32_t flags, double* pcm_out, void* stream, int fpc, long long clip_stride);
+}  // namespace
+extern "C" {
+
 int frad_p0_digital(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C, int32_t bits,
                     uint32_t flags, double* pcm_out, void* stream) {
+    return p0_digital_impl(payload, payload_stride, n_frames, N, C, bits, flags, pcm_out, stream, 0, 0);
+}
+
+int frad_p0_digital_clips(const void* payload, int64_t payload_stride, int64_t n_clips, int32_t frames_per_clip, int32_t N, int32_t C,
+                          int32_t bits, uint32_t flags, double* pcm_out, int64_t out_clip_stride, void* stream) {
+    if (n_clips < 0 || frames_per_clip < 1 || N < 1 || out_clip_stride < (int64_t)frames_per_clip * N) return FRAD_E_INVALID;
+    if (n_clips > 0x7fffffffLL / frames_per_clip) return FRAD_E_UNSUPPORTED;
+    return p0_digital_impl(payload, payload_stride, n_clips * frames_per_clip, N, C, bits, flags, pcm_out, stream, frames_per_clip, out_clip_stride);
+}
+
+}  // extern "C"
+namespace {
+
+int p0_digital_impl(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C, int32_t bits,
+                    uint32_t flags, double* pcm_out, void* stream, int fpc, long long clip_stride) {
     int rc = check_common(payload, pcm_out, n_frames, N, C, bits);
     if (rc != FRAD_OK) return rc;
     if (n_frames == 0) return FRAD_OK;
     if (payload_stride < (int64_t)frad_payload_bytes(N, C, bits)) return FRAD_E_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
     Geom g = make_geom(n_frames, N, C, N, payload_stride, bits, flags, FRAD_PCM_F64LE);
+    g.fpc = fpc; g.clip_stride = clip_stride;
     const int ai = (aligned16(payload) && payload_stride % 16 == 0) ? 1 : 0;
     const unsigned char* in = static_cast<const unsigned char*>(payload);
-    if (launch_p0_inv_wave(s, in, pcm_out, g, ai, aligned16(pcm_out) ? 1 : 0, unit_neg)) { HIPCHK(hipGetLastError()); return FRAD_OK; }
+    const int aout = (aligned16(pcm_out) && (fpc == 0 || ((clip_stride * C) * 8) % 16 == 0)) ? 1 : 0;
+    if (launch_p0_inv_wave(s, in, pcm_out, g, ai, aout, unit_neg)) { HIPCHK(hipGetLastError()); return FRAD_OK; }
     const FastCfg c = fast_cfg(N, C, false);
+    if (fpc > 0 && c.ok) {
+        // clips through a kernel without clip addressing: the flat batch decodes into a dense scratch, one strided copy scatters it
+        const size_t row = (size_t)fpc * N * C * 8;
+        StreamScratch ws{s};
+        if (hipMallocAsync(&ws.p, row * (size_t)(n_frames / fpc), s) != hipSuccess) return FRAD_E_NOMEM;
+        rc = p0_digital_impl(payload, payload_stride, n_frames, N, C, bits, flags, static_cast<double*>(ws.p), stream, 0, 0);
+        if (rc != FRAD_OK) return rc;
+        HIPCHK(hipMemcpy2DAsync(pcm_out, (size_t)clip_stride * C * 8, ws.p, row, row, (size_t)(n_frames / fpc), hipMemcpyDeviceToDevice, s));
+        return FRAD_OK;
+    }
     if (c.ok) {
         Tables tb; rc = get_tables(c.log2m, false, tb);
         if (rc != FRAD_OK) return rc;
@@ -474,6 +548,15 @@ int frad_p0_digital(const void* payload, int64_t payload_stride, int64_t n_frame
         const int r = launch_p0_inv_blue(s, in, pcm_out, g, ai);
         if (r < 0) { if (r == FRAD_E_HIP) g_last_hip = blue_last_hip_error(); return r; }
         if (r == 1) { HIPCHK(hipGetLastError()); return FRAD_OK; }
+        if (fpc > 0) {                                       // (Bluestein did not take it) flat batch into a scratch, then scatter
+            const size_t row = (size_t)fpc * N * C * 8;
+            StreamScratch ws{s};
+            if (hipMallocAsync(&ws.p, row * (size_t)(n_frames / fpc), s) != hipSuccess) return FRAD_E_NOMEM;
+            rc = p0_digital_impl(payload, payload_stride, n_frames, N, C, bits, flags, static_cast<double*>(ws.p), stream, 0, 0);
+            if (rc != FRAD_OK) return rc;
+            HIPCHK(hipMemcpy2DAsync(pcm_out, (size_t)clip_stride * C * 8, ws.p, row, row, (size_t)(n_frames / fpc), hipMemcpyDeviceToDevice, s));
+            return FRAD_OK;
+        }
         const size_t per_frame = 2 * (size_t)N * C * 8;
         if (per_frame > (size_t)kLdsBytes) {
             const int r = global_p0_digital(in, pcm_out, g, flags, s);
@@ -493,4 +576,4 @@ int frad_p0_digital(const void* payload, int64_t payload_stride, int64_t n_frame
     return FRAD_OK;
 }
 
-}  // extern "C"
+}  // namespace

@@ -39,7 +39,16 @@ struct Geom {
     int cc_fast;                // FFT kernels, payload side: 1 or 2 = pairwise 16-byte LDS path for C = 1 / 2
     int* ovf_flag;              // frad_p0_analogue_checked: set to 1 when a frame's |X| max exceeds ovf_limit (else untouched); may be null
     double ovf_limit;
+    int fpc;                    // frames per clip of the PCM side ( > 0: frad_p0_*_clips; 0: one flat run of frames)
+    long long clip_stride;      // sample-frames between consecutive clips
 };
+// first sample-frame of frame f on the PCM side: i * frame_stride, or -- a batch of equally cut clips, encoder.py:72-93 per
+// clip -- clip * clip_stride + (frame inside the clip) * frame_stride.  (n_frames < 2^31 whenever fpc is set.)
+__device__ __forceinline__ long long frame_base(const Geom& g, long long f) {
+    if (g.fpc <= 0) return f * g.frame_stride;
+    const unsigned c = (unsigned)f / (unsigned)g.fpc;
+    return (long long)c * g.clip_stride + (long long)((unsigned)f - c * (unsigned)g.fpc) * g.frame_stride;
+}
 
 __device__ __forceinline__ bool dtype_is_f32_class(int code) { return (code >> 3) == 2 && ((code >> 1) & 3) <= 2; }
 
@@ -817,7 +826,7 @@ __device__ FRAD_NOINLINE void store_pcm_f64(int smem_off, double* __restrict__ o
     const int N = g.N, C = g.C, NC = N * C;
     const int pairs = NC / 2;                       // out + f*NC is 16-byte aligned when NC is even
     for (int fl = 0; fl < nfl; ++fl) {
-        double* dst = out + (f0 + fl) * (long long)NC;
+        double* dst = out + frame_base(g, f0 + fl) * C;       // (decode: frame_stride = N)
         if ((NC & 1) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
             for (int p = threadIdx.x; p < pairs; p += blockDim.x) {
                 const int e = 2 * p;

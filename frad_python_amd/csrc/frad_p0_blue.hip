@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(1024) k_p0_fwd_blue(const unsigned char* __res
     cx<double>* buf = bufs + (long long)cf * L;
     const int xoff = cg * L * 16;
     double* X = reinterpret_cast<double*>(smem + xoff);
-    const unsigned char* src = pcm + ((f * g.frame_stride * C) << LG);
+    const unsigned char* src = pcm + ((frame_base(g, f) * C) << LG);
     const double inv_n = 1.0 / (double)N;
     const bool whole = g.in_mode != 0;                       // X area holds all C channels: one whole-frame pack at the end
     if (g.cc_fast) {

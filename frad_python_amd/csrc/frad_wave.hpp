@@ -806,7 +806,6 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably wave-uniform: unit numbers and frame bases stay in SGPRs
 #endif
     unsigned char* wbuf = smem + kWaveTableBytes + wv * kWaveBufBytes;
-    const long long frameb = (g.frame_stride * CC) << LG;
     const long long n_units = (g.n_frames + FPW - 1) / FPW;
     // units [ub, ue) belong to this block; its waves draw them from an LDS counter (the first kWaveWaves statically)
     const long long ub = n_units * blockIdx.x / gridDim.x, ue = n_units * (blockIdx.x + 1) / gridDim.x;
@@ -826,7 +825,7 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
     auto dma_in = [&](long long u) {
         if constexpr (STAGED) {
             const int h = lane >> 5, l = lane & 31;
-            const unsigned char* src = pcm + frame_of(u, h) * frameb + (CC == 2 ? lane : l) * 16;
+            const unsigned char* src = pcm + ((frame_base(g, frame_of(u, h)) * CC) << LG) + (CC == 2 ? lane : l) * 16;
 #pragma unroll
             for (int i = 0; i < NDMA; ++i) {
 #ifdef FRAD_HOST_EMULATION
@@ -933,7 +932,7 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
             team_sync<64>();                                   // raw bytes consumed: the buffer may be overwritten
         } else {
             // ---- wide elements: one global load per element, no staging ---------------------------
-            const unsigned char* fb = pcm + frame_of(u, h) * frameb + (CC == 2 ? (h << LG) : 0);
+            const unsigned char* fb = pcm + ((frame_base(g, frame_of(u, h)) * CC) << LG) + (CC == 2 ? (h << LG) : 0);
             dispatch_pcm<LG>(g.dtype, g.raw_be, [&](auto code_tag, auto raw_tag) {
                 constexpr int CODE = decltype(code_tag)::value;
                 constexpr bool RAW = decltype(raw_tag)::value != 0;
@@ -1561,7 +1560,8 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
             const bool live = f < g.n_frames;
             int lq = l, hq = h;
             FRAD_OPAQUE(lq); FRAD_OPAQUE(hq);
-            unsigned char* dstf = reinterpret_cast<unsigned char*>(out + (live ? f : 0) * (long long)N * CC);
+            const long long fbase = frame_base(g, live ? f : 0);      // first sample-frame of the output frame (frame_stride = N)
+            unsigned char* dstf = reinterpret_cast<unsigned char*>(out + fbase * CC);
             // staging position of local sample-frame S = 4 n + r (n = lane's quad inside the block, r = 0..3), see header:
             //   CC == 2: 16-byte rows R = S, physical row R ^ ((R >> 3) & 7), channel h in the row's half
             //   CC == 1: 8-byte slots S of frame h (4 KiB per frame and group), physical slot S ^ (((S >> 4) & 3) << 1)
@@ -1598,7 +1598,7 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
                     // staged 16-byte pairs; the slot swizzle permutes pairs inside a 16-slot run), converts them and stores
                     // 8 x itemsize contiguous bytes
                     constexpr int okind = OUT >> 3, olg = (OUT >> 1) & 3, osz = 1 << olg;
-                    unsigned char* dn = reinterpret_cast<unsigned char*>(out) + ((live ? f : 0) * (long long)N + 512 * gq) * osz;
+                    unsigned char* dn = reinterpret_cast<unsigned char*>(out) + (fbase + 512 * gq) * osz;
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
                         v4u r4[4];
@@ -1633,7 +1633,7 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
                     // narrowed output: lane t of half hf takes sample-frames 256 hf + 4 t .. + 3 of the group (four staged rows),
                     // converts the eight values and stores 8 x itemsize contiguous bytes
                     constexpr int okind = OUT >> 3, olg = (OUT >> 1) & 3, osz = 1 << olg;
-                    unsigned char* dn = reinterpret_cast<unsigned char*>(out) + ((live ? f : 0) * (long long)N + 512 * gq) * (2 * osz);
+                    unsigned char* dn = reinterpret_cast<unsigned char*>(out) + (fbase + 512 * gq) * (2 * osz);
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
                         v4u r4[4];

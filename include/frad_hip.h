@@ -103,6 +103,21 @@ int frad_p0_overflow_scan(const double* absmax, int64_t n_frames, int32_t bits, 
 int frad_p0_digital(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C,
                     int32_t bits, uint32_t flags, double* pcm_out, void* stream);
 
+/* A batch of equally cut CLIPS consumed and produced in place (BASELINE config 3: 4096 x 1 s clips; the reference cuts
+ * every clip into frames on its own, src/libfrad/encoder.py:72-93, and its decoder returns them clip by clip):
+ * frad_p0_analogue_clips == frad_p0_analogue_checked over frames (clip c, i), i < frames_per_clip, read at
+ * pcm + (c*clip_stride + i*N) sample-frames -- the resident layout [n_clips, clip_stride, C] -- with the payloads dense,
+ * frame c*frames_per_clip + i at payload + (c*frames_per_clip + i)*payload_stride (absmax likewise; overflow_flag may be
+ * NULL).  A clip's shorter last frame is one more call with frames_per_clip = 1, its own N, and `pcm` advanced to the first
+ * clip's tail.  frad_p0_digital_clips == frad_p0_digital writing frame (c, i) at pcm_out + (c*out_clip_stride + i*N)*C.
+ * The N = 2048 wave kernels and the any-N Bluestein kernels address clips themselves; every other geometry goes through
+ * one strided device copy to / from stream-ordered scratch.  clip_stride >= frames_per_clip*N.                       */
+int frad_p0_analogue_clips(const void* pcm, int32_t pcm_dtype, int64_t n_clips, int64_t clip_stride, int32_t frames_per_clip,
+                           int32_t N, int32_t C, int32_t bits, uint32_t flags, void* payload, int64_t payload_stride,
+                           double* absmax, int32_t* overflow_flag, void* stream);
+int frad_p0_digital_clips(const void* payload, int64_t payload_stride, int64_t n_clips, int32_t frames_per_clip, int32_t N,
+                          int32_t C, int32_t bits, uint32_t flags, double* pcm_out, int64_t out_clip_stride, void* stream);
+
 /* ---- profile 4: PCM archiving (same pack/unpack, no transform; profile4.py:14-41, 43-63) ------
  * float32/float16 PCM is cast from single precision, everything else from float64, as numpy's
  * astype does on the reference's arrays.                                                          */

@@ -146,7 +146,7 @@ inline float __double2float_rz(double d) {
 typedef int hipError_t;
 constexpr hipError_t hipSuccess = 0;
 typedef void* hipStream_t;
-enum { hipMemcpyHostToDevice = 1, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToDevice = 3, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 enum { hipDeviceAttributeMultiprocessorCount = 1 };
 inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 3; return hipSuccess; }
@@ -155,6 +155,10 @@ inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 template <typename P> inline hipError_t hipMallocAsync(P** p, size_t n, hipStream_t) { return hipMalloc(p, n); }
 inline hipError_t hipFreeAsync(void* p, hipStream_t) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, int, hipStream_t) {
+    for (size_t r = 0; r < height; ++r) std::memcpy(static_cast<char*>(d) + r * dpitch, static_cast<const char*>(s) + r * spitch, width);
+    return hipSuccess;
+}
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 struct hipDeviceProp_t { size_t maxSharedMemoryPerMultiProcessor = 163840, sharedMemPerBlockOptin = 163840; int multiProcessorCount = 1; };

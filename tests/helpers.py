@@ -63,6 +63,22 @@ class EmuBackend:
         fn(buf.ctypes.data + offset, stride, F, N, C, bits, int(le), out.ctypes.data)
         return out[:F]
 
+    def clips(self, raw: np.ndarray, fmt, N, bits, first=0, fpc=None):
+        """frad_p0_analogue_clips + frad_p0_digital_clips over raw [n_clips, clip_len, C] -> (payload rows, absmax, decoded clips)"""
+        from frad_python_amd.backend.pcmformat import pcm_dtype_code
+        n_clips, clip_len, C = raw.shape
+        fpc = (clip_len - first) // N if fpc is None else fpc
+        pb = self.lib.payload_bytes(N, C, bits); stride = _align16(pb)
+        src = np.zeros(raw.nbytes + 64, np.uint8); src[:raw.nbytes] = raw.view(np.uint8).reshape(-1)
+        F = n_clips * fpc
+        pay = np.zeros(F * stride + 64, np.uint8); am = np.zeros(F)
+        flag = np.zeros(1, np.int32)
+        self.lib.p0_analogue_clips(src.ctypes.data + first * C * raw.itemsize, pcm_dtype_code(fmt), n_clips, clip_len, fpc, N, C, bits, 2,
+                                   pay.ctypes.data, stride, am.ctypes.data, flag.ctypes.data)
+        out = np.full((n_clips, clip_len, C), -7.0)
+        self.lib.p0_digital_clips(pay.ctypes.data, stride, n_clips, fpc, N, C, bits, 0, out.ctypes.data + first * C * 8, clip_len)
+        return pay[:F * stride].reshape(F, stride)[:, :pb].copy(), am, out
+
     def crc32_frames(self, rows: np.ndarray, nbytes, offset=0):
         F, stride = rows.shape
         buf = np.zeros(F * stride + offset + 64, np.uint8)
@@ -180,6 +196,17 @@ class GpuBackend:
         out = core.digital_batch(profile, view, F, N, C, bits, le, payload_stride=stride)
         t.cuda.synchronize()
         return out.cpu().numpy()
+
+    def clips(self, raw: np.ndarray, fmt, N, bits, first=0, fpc=None):
+        from frad_python_amd import core
+        t = self.torch
+        n_clips, clip_len, C = raw.shape
+        dev_raw = t.from_numpy(raw.copy()).to(self.dev)
+        enc = core.analogue_clips(dev_raw, fmt, N, bits, first=first, frames_per_clip=fpc)
+        out = t.full((n_clips, clip_len, C), -7.0, dtype=t.float64, device=self.dev)
+        core.digital_clips(enc.payload, out, N, bits, first=first, frames_per_clip=fpc)
+        t.cuda.synchronize()
+        return enc.payload[:, :enc.nbytes].cpu().numpy(), enc.absmax.cpu().numpy(), out.cpu().numpy()
 
     def crc32_frames(self, rows: np.ndarray, nbytes, offset=0):
         from frad_python_amd import core

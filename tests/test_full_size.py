@@ -90,6 +90,38 @@ def test_cfg3_clip_batch_sharded_like_eight_gpus(gpu):
     want = fo.unpack_floats(fo.pack_floats(fo.dct_channels(frame).T.ravel(), 32, False), 32, False)
     got = fo.unpack_floats(et.payload[3, :et.nbytes].cpu().numpy().tobytes(), 32, False)
     assert np.max(np.abs(got - want)) <= 2.0 ** -22 * np.max(np.abs(want))
+    # the same batch consumed and produced IN PLACE (frad_p0_analogue_clips / _digital_clips): [clips, 48000, C] as it is
+    # resident, no gathered copies -- bit-identical to the gathered batches above
+    ec = core.analogue_clips(pcm, "s16le", N, 32)
+    assert torch.equal(ec.payload, enc.payload) and torch.equal(ec.absmax, enc.absmax)
+    etc = core.analogue_clips(pcm, "s16le", tail, 32, first=full * N)
+    assert torch.equal(etc.payload, et.payload) and torch.equal(etc.absmax, et.absmax)
+    whole = torch.full((clips, n, C), float("nan"), dtype=torch.float64, device=dev)
+    core.digital_clips(ec.payload, whole, N, 32)
+    core.digital_clips(etc.payload, whole, tail, 32, first=full * N)
+    db = core.digital_batch(0, enc.payload, clips * full, N, C, 32)
+    assert torch.equal(whole[:, :full * N].reshape(clips * full, N, C), db)
+    assert torch.equal(whole[:, full * N:], dt)
+
+
+def test_clip_batches_of_other_geometries(gpu):
+    """frad_p0_*_clips beyond the kernels that address clips themselves: every geometry gives the flat batch's bits
+    (N = 1024 unit kernels, N = 4096 eight-channel float32, an odd frame length with float32 PCM, mono N = 2048 with an
+    odd number of frames per clip)."""
+    torch, core, dev = gpu
+    for (N, C, fmt, clip_len, n_clips) in ((1024, 2, "s16le", 5000, 9), (4096, 8, "f32le", 9000, 3), (300, 3, "f32le", 1000, 5),
+                                           (2048, 1, "s16le", 7 * 2048 + 8, 5), (2048, 2, "s32le", 3 * 2048 + 4, 4)):
+        pcm = _signal(torch, dev, n_clips * clip_len, C, N + C, fmt).reshape(n_clips, clip_len, C)
+        fpc = clip_len // N
+        body = pcm[:, :fpc * N].contiguous()
+        flat = core.analogue_batch(0, body, fmt, n_clips * fpc, N, C, 32, check_overflow=False)
+        ec = core.analogue_clips(pcm, fmt, N, 32)
+        assert torch.equal(ec.payload, flat.payload) and torch.equal(ec.absmax, flat.absmax), (N, C, fmt)
+        out = torch.zeros((n_clips, clip_len, C), dtype=torch.float64, device=dev)
+        core.digital_clips(ec.payload, out, N, 32)
+        want = core.digital_batch(0, flat.payload, n_clips * fpc, N, C, 32)
+        assert torch.equal(out[:, :fpc * N].reshape(n_clips * fpc, N, C), want), (N, C, fmt)
+        assert float(out[:, fpc * N:].abs().max()) == 0.0       # nothing written behind the last whole frame
 
 
 def test_cfg4_192k_eight_channel_float32(gpu):

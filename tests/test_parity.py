@@ -198,6 +198,32 @@ def test_overlapped_frame_gather(be):
             assert np.array_equal(pay[f], ref[f][0])
 
 
+@pytest.mark.parametrize("geom", [(2048, 2, "s16le", 3 * 2048 + 8, 5), (2048, 1, "s16le", 3 * 2048 + 16, 3), (896, 2, "s16le", 1000, 4),
+                                  (1024, 2, "s16le", 2 * 1024 + 104, 3), (300, 3, "f32le", 700, 3)])
+def test_clip_batches_in_place(be, geom):
+    """frad_p0_analogue_clips / frad_p0_digital_clips (BASELINE config 3's layout, encoder.py:72-93 per clip): the frames of
+    [n_clips, clip_len, C] read and written in place give the bits of the gathered flat batch -- through the kernels that
+    address clips themselves (N = 2048 wave kernels, Bluestein) and through the strided-copy route of the others."""
+    N, C, fmt, clip_len, n_clips = geom
+    dt = fo.pcm_dtype(fmt)
+    raw = synth.to_pcm(synth.harmonic_mix(n_clips * clip_len, C, 48000, seed=N + C), fmt).reshape(n_clips, clip_len, C)
+    fpc = clip_len // N
+    pay, am, out = be.clips(raw, fmt, N, 32)
+    body = np.ascontiguousarray(raw[:, :fpc * N]).reshape(-1, C)
+    want_pay, want_am = be.analogue(0, body, fmt, n_clips * fpc, N, C, 32, False)
+    assert np.array_equal(pay, want_pay) and np.array_equal(am, want_am)
+    want_out = be.digital(0, want_pay, n_clips * fpc, N, C, 32, False)
+    assert np.array_equal(out[:, :fpc * N].reshape(-1, N, C), want_out)
+    assert np.all(out[:, fpc * N:] == -7.0)                    # nothing written behind the last whole frame
+    # the clip's short last frame as a second batch (frames_per_clip = 1)
+    tail = clip_len - fpc * N
+    if tail >= 4 and (tail * C * dt.itemsize) % 16 == 0 or tail >= 4:
+        tp, ta, tout = be.clips(raw, fmt, tail, 32, first=fpc * N, fpc=1)
+        wp, wa = be.analogue(0, np.ascontiguousarray(raw[:, fpc * N:]).reshape(-1, C), fmt, n_clips, tail, C, 32, False)
+        assert np.array_equal(tp, wp) and np.array_equal(ta, wa)
+        assert np.array_equal(tout[:, fpc * N:], be.digital(0, wp, n_clips, tail, C, 32, False))
+
+
 def test_nan_inf_scrub_and_absmax_semantics(be, g5):
     pay = g5["scrub_payload"].reshape(1, -1)
     assert np.array_equal(be.digital(4, pay, 1, 8, 1, 32, False)[0], g5["scrub_p4_dec"])
