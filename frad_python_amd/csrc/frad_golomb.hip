@@ -342,32 +342,30 @@ __global__ void __launch_bounds__(64) k_gol_decode(const unsigned char* __restri
 }
 
 // ---- decode, one WAVE per frame (the fast path) ----------------------------------------------------------------------
-// The sequential dependency of a prefix code is broken in two phases.  The stream sits in LDS; lane i owns the bits
-// [i CHB, (i+1) CHB).  Phase 1, all lanes at once: walking its chunk backwards, a lane computes for every bit position p
-// "if a code started here, how many codes start before my chunk ends and at which offset does the next chunk get
-// entered" -- entry(p) = entry(p + 2 z(p) + k + 1) + 1 code, a ring of the last 64 positions is all it needs -- so that
-// at the end the ring holds that map for the first 64 bits of the chunk.  Phase 2: 64 dependent look-ups chain the maps
-// (entry offset and output index of every chunk).  Phase 3, all lanes at once: each decodes its own ~1/64 of the codes.
-// Codes longer than 64 bits, k > 30 and streams beyond the LDS budget are left to the lane-per-frame kernel (`todo`).
+// The sequential dependency of a prefix code is broken in two phases.  The stream sits in LDS as big-endian words; lane i owns
+// the bits [i CHB, (i+1) CHB), CHB a multiple of 32.  Phase 1, all lanes at once: walking its chunk backwards, a lane computes
+// for every bit position p "if a code started here, how many codes start before my chunk ends and at which offset is the
+// next chunk entered" -- entry(p) = entry(p + 2 z(p) + k + 1) + one code, z(p) the zero run at p -- in a ring of the last 64
+// positions (16-bit entries), so that at the end the ring holds that map for the first positions of the chunk.  A code is at
+// least k + 1 bits long, so k + 1 consecutive positions do not depend on each other: for k >= 3 they are taken four at a
+// time (four ring reads in flight per LDS round trip).  Phase 2: 64 dependent look-ups chain the maps (entry offset, output
+// index and code count of every chunk).  Phase 3, all lanes at once: each decodes exactly its own codes from a 64-bit
+// window over the LDS words.  Codes longer than 32 bits, k > 30, more than 511 codes per chunk and streams beyond the LDS
+// budget are left to the lane-per-frame kernel (`todo`).
 constexpr int GW_WORDS = 6144;             // most stream words a wave holds in LDS (24 KiB); the launch sizes it for 16 bits per value
-constexpr int GW_E = 64;                   // longest code / entry range handled here
-constexpr int GW_PITCH = 65;               // ring pitch in words (odd: lanes hit different banks)
-constexpr int gw_lds(int wmax) { return (wmax + 2) * 4 + 64 * GW_PITCH * 4; }
-constexpr uint32_t GW_END = 255, GW_LONG = 254;
-
-__device__ __forceinline__ uint32_t gw_bits(const uint32_t* words, long long pos, int n) {      // n in [1, 32], MSB first
-    const long long w = pos >> 5; const int off = (int)(pos & 31);
-    const u64 two = ((u64)words[w] << 32) | (u64)words[w + 1];
-    return (uint32_t)((two << off) >> (64 - n));
-}
+constexpr int GW_E = 32;                   // longest code / entry range handled here
+constexpr int GW_RING = 64;                // ring entries per lane (>= GW_E + the four positions of a batch)
+constexpr int GW_PITCH = 66;               // ring pitch in 16-bit entries (33 words: odd, lanes hit different banks)
+constexpr int gw_lds(int wmax) { return (wmax + 2) * 4 + 64 * GW_PITCH * 2; }
+constexpr uint32_t GW_END = 127, GW_LONG = 126;          // low 7 bits of an entry: exit offset 0 .. 31, or one of these; high 9 bits: codes
 
 // one stream of the calling WAVE's frame; false = leave it to the slow kernel (nothing written)
 __device__ __forceinline__ bool decode_stream_2phase(const unsigned char* p, long long len, int32_t* __restrict__ out, long long cap, int wmax) {
     FRAD_DYN_SMEM(smem_);
     uint32_t* words = reinterpret_cast<uint32_t*>(smem_);
-    uint32_t* ring = words + wmax + 2 + (threadIdx.x & 63) * GW_PITCH;
-    const uint32_t* rings = words + wmax + 2;
+    unsigned short* rings = reinterpret_cast<unsigned short*>(words + wmax + 2);
     const int lane = threadIdx.x & 63;
+    unsigned short* ring = rings + lane * GW_PITCH;
     const long long nbytes = len >= 1 ? len - 1 : 0;
     long long total = 0;
     if (nbytes > 0 && cap > 0) {
@@ -375,98 +373,122 @@ __device__ __forceinline__ bool decode_stream_2phase(const unsigned char* p, lon
         const unsigned char* bits = p + 1;
         const int lead = (int)(reinterpret_cast<uintptr_t>(bits) & 3);
         const unsigned char* a0 = bits - lead;
-        const long long nwords = (lead + nbytes + 3) >> 2;
-        if (nwords > wmax || k > 30) return false;
-        const long long T = (long long)lead * 8 + nbytes * 8;    // end of the stream in word space; it starts at bit lead * 8
+        const long long nwords_ll = (lead + nbytes + 3) >> 2;
+        if (nwords_ll > wmax || k > 30) return false;
+        const int nwords = (int)nwords_ll;
+        const int T = lead * 8 + (int)nbytes * 8;                 // end of the stream in word space; it starts at bit lead * 8
         FRAD_LDS_BARRIER();                                       // the previous stream's phases are done with the LDS
-        for (long long w = lane; w < nwords + 2; w += 64) {
+        int last1 = -1;                                           // position of the stream's last '1'
+        for (int w = lane; w < nwords + 2; w += 64) {
             uint32_t v = 0;
             if (w < nwords) {
                 v = bswap32(*FRAD_GCPTR(uint32_t, a0 + 4 * w));
                 if (w == 0 && lead) v &= 0xffffffffu >> (8 * lead);          // bytes before the stream
-                const long long hi = (w + 1) * 32;
-                if (hi > T) v = (T - w * 32) > 0 ? v & ~(0xffffffffu >> (int)(T - w * 32)) : 0u;      // bytes after it
+                const int hi = (w + 1) * 32;
+                if (hi > T) v = (T - w * 32) > 0 ? v & ~(0xffffffffu >> (T - w * 32)) : 0u;      // bytes after it
             }
             words[w] = v;
+            if (v) { const int p1 = w * 32 + 31 - __builtin_ctz(v); last1 = p1 > last1 ? p1 : last1; }
         }
+        for (int off = 1; off < 64; off <<= 1) { const int o = (int)__shfl_xor((unsigned long long)(unsigned)last1, off, 64); last1 = o > last1 ? o : last1; }
         FRAD_LDS_BARRIER();
-        long long chb = (T + 63) / 64;
-        if (chb < GW_E) chb = GW_E;
-        const long long nch = (T + chb - 1) / chb;
-        const long long cs = lane * chb, ce = cs + chb < T ? cs + chb : T;
+        int chb = ((T + 63) / 64 + 31) & ~31;                     // whole words per chunk
+        if (chb < 32) chb = 32;
+        if (chb / (k + 1) > 511) return false;                    // the 9-bit code count of an entry
+        const int nch = (T + chb - 1) / chb;
+        const int cs = lane * chb, ce = cs + chb;
         // ---- phase 1: the entry map of this lane's chunk ---------------------------------------------------
         if (lane < nch) {
-            // zero run at the chunk's end (it continues into the next chunk): scan ahead, at most GW_E + 1 bits
-            int z = 0; bool inf = false;
+            // zero run at the chunk's end (it continues into the next chunk); 33 stands for "33 or more"
+            int z;
             {
-                long long q = ce;
-                while (z <= GW_E) {
-                    if (q >= T) { inf = true; break; }
-                    const int n = (int)(T - q < 32 ? T - q : 32);
-                    const uint32_t v = gw_bits(words, q, n) << (32 - n);
-                    if (v == 0) { z += n; q += n; continue; }
-                    z += __builtin_clz(v); break;
-                }
+                const int wn = ce >> 5;                                   // (the last chunks may reach beyond the staged words: zeros)
+                const uint32_t w0 = wn < nwords + 2 ? words[wn] : 0u, w1 = wn + 1 < nwords + 2 ? words[wn + 1] : 0u;
+                z = w0 ? __builtin_clz(w0) : (w1 ? 32 + __builtin_clz(w1) : 33);
+                if (z > 33) z = 33;
             }
-            uint32_t cur = 0;
-            for (long long pp = ce - 1; pp >= cs; --pp) {
-                if ((pp & 31) == 31 || pp == ce - 1) cur = words[pp >> 5];
-                const bool one = (cur >> (31 - (int)(pp & 31))) & 1u;
-                if (one) { z = 0; inf = false; } else if (z <= GW_E) ++z;
-                uint32_t e;
-                if (inf) e = GW_END;                                              // zeros to the end: no code starts here
-                else {
-                    const int clen = 2 * z + k + 1;
-                    const long long nx = pp + clen;
-                    if (clen > GW_E) e = GW_LONG;
-                    else if (nx >= T) e = (1u << 8) | GW_END;                     // the stream's last code (maybe cut short)
-                    else if (nx >= ce) e = (1u << 8) | (uint32_t)(nx - ce);
-                    else {
-                        const uint32_t t = ring[(int)((nx - cs) & 63)];
-                        e = (t & 255u) == GW_LONG ? GW_LONG : t + (1u << 8);
+            // entry of position pp given the zero run z there: either final (`e`, ri < 0) or one more code behind ring slot `ri`.
+            // Branch-free (selects): the lanes of a wave sit in different cases at every position.
+            auto classify = [&](int pp, int z_, uint32_t& e, int& ri) {
+                const int clen = 2 * z_ + k + 1, nx = pp + clen;
+                const bool end_ = pp > last1, lng = clen > GW_E, lastc = nx >= T, outc = nx >= ce;
+                uint32_t v = (1u << 7) | ((uint32_t)(nx - ce) & 127u);            // the code ends in the next chunk
+                v = lastc ? ((1u << 7) | GW_END) : v;                             // the stream's last code (maybe cut short)
+                v = lng ? GW_LONG : v;
+                v = end_ ? GW_END : v;                                            // zeros to the end: no code starts here
+                e = v;
+                const int slot = (nx - cs) & (GW_RING - 1);
+                ri = (end_ | lng | lastc | outc) ? (slot | (int)0x80000000) : slot;     // sign bit: the ring is not consulted
+            };
+            auto finish = [&](uint32_t e, int ri, uint32_t t) -> uint32_t {
+                const uint32_t viaring = (t & 127u) == GW_LONG ? GW_LONG : t + (1u << 7);
+                return ri < 0 ? e : viaring;
+            };
+            for (int w = (ce >> 5) - 1; w >= (cs >> 5); --w) {
+                const uint32_t cur = w < nwords + 2 ? words[w] : 0u;
+                if (k >= 3) {
+#pragma unroll 2
+                    for (int i = 0; i < 32; i += 4) {                 // positions 32 w + 31 - i ... - 3: mutually independent (k + 1 >= 4)
+                        uint32_t e[4]; int ri[4]; uint32_t t[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool one = (cur >> (i + j)) & 1u;
+                            z = one ? 0 : (z < 33 ? z + 1 : 33);
+                            classify(32 * w + 31 - i - j, z, e[j], ri[j]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) t[j] = ring[ri[j] & (GW_RING - 1)];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ring[(32 * w + 31 - i - j - cs) & (GW_RING - 1)] = (unsigned short)finish(e[j], ri[j], t[j]);
+                    }
+                } else {
+                    for (int i = 0; i < 32; ++i) {
+                        const bool one = (cur >> i) & 1u;
+                        z = one ? 0 : (z < 33 ? z + 1 : 33);
+                        uint32_t e; int ri;
+                        classify(32 * w + 31 - i, z, e, ri);
+                        const uint32_t t = ring[ri & (GW_RING - 1)];
+                        ring[(32 * w + 31 - i - cs) & (GW_RING - 1)] = (unsigned short)finish(e, ri, t);
                     }
                 }
-                ring[(int)((pp - cs) & 63)] = e;
             }
         }
         FRAD_LDS_BARRIER();
         // ---- phase 2: chain the maps (every lane walks the same chain and keeps its own link) -----------------
-        long long my_base = 0, my_cnt = 0; int my_entry = 0;
+        int my_base = 0, my_cnt = 0, my_entry = 0;
         {
-            int e = lead * 8; long long base = 0; bool ended = false, bad = false;
-            for (long long i = 0; i < nch; ++i) {
+            int e = lead * 8, base = 0; bool ended = false, bad = false;
+            for (int i = 0; i < nch; ++i) {
                 if (!ended) {
-                    const uint32_t t = rings[(int)i * GW_PITCH + e];
-                    const uint32_t x = t & 255u;
+                    const uint32_t t = rings[i * GW_PITCH + e];
+                    const uint32_t x = t & 127u;
                     if (x == GW_LONG) { bad = true; break; }
-                    if (i == lane) { my_base = base; my_entry = e; my_cnt = (long long)(t >> 8); }
-                    base += (long long)(t >> 8);
+                    if (i == lane) { my_base = base; my_entry = e; my_cnt = (int)(t >> 7); }
+                    base += (int)(t >> 7);
                     if (x == GW_END) ended = true; else e = (int)x;
                 }
             }
-            if (bad) return false;                                                // (uniform: every lane read the same words)
+            if (bad) return false;                                                // (uniform: every lane read the same entries)
             total = base < cap ? base : cap;
         }
         // ---- phase 3: every lane decodes the codes that start in its chunk ------------------------------------
-        if (lane < nch) {                                             // exactly the codes phase 1 counted for this chunk
-            long long pos = cs + my_entry, idx = my_base;
-            for (long long c = 0; c < my_cnt && idx < cap; ++c) {
-                // zeros up to the '1' (phase 1 guarantees there is one before T and that the code is <= 64 bits)
-                int z = 0;
-                for (;;) {
-                    const int n = (int)(T - pos < 32 ? T - pos : 32);
-                    if (n <= 0) break;                                          // (cannot happen: phase 1 saw the '1'; never spin)
-                    const uint32_t v = gw_bits(words, pos, n) << (32 - n);
-                    if (v == 0) { z += n; pos += n; continue; }
-                    const int c = __builtin_clz(v); z += c; pos += c; break;
-                }
-                long long want = z + k + 1;
-                if (want > T - pos) want = T - pos;                               // cut short by the end of the buffer
-                if (want <= 0) break;
-                u64 val = 0;
-                if (want > 32) { val = gw_bits(words, pos, (int)(want - 32)); pos += want - 32; want = 32; }
-                val = (val << want) | gw_bits(words, pos, (int)want);
-                pos += want;
+        if (lane < nch && my_cnt > 0) {                               // exactly the codes phase 1 counted for this chunk: each has its
+            int pos = cs + my_entry;                                  // '1' before T and is at most GW_E bits long
+            long long idx = my_base;
+            int wi = pos >> 5;
+            // 64-bit window, left-aligned at `pos`; `have` valid bits (the words beyond the stream are zero)
+            u64 win = (((u64)words[wi] << 32) | (u64)words[wi + 1]) << (pos & 31);
+            int have = 64 - (pos & 31);
+            wi += 2;
+            for (int c = 0; c < my_cnt && idx < cap; ++c) {
+                if (have < 32) { win |= (u64)words[wi < nwords + 2 ? wi : nwords + 1] << (32 - have); have += 32; ++wi; }
+                const int z = __builtin_clz((uint32_t)(win >> 32) | 1u);        // <= 15 here (the code fits 32 bits)
+                int want = z + k + 1;                                           // bits from the '1' on
+                const int left = T - (pos + z);
+                if (want > left) want = left;                                   // cut short by the end of the buffer
+                const int used = z + want;
+                const u64 val = want > 0 ? (win << z) >> (64 - want) : 0ull;
+                win <<= used; have -= used; pos += used;
                 const long long n = (long long)val - (1LL << k);
                 out[idx++] = sat32((n & 1) ? (n + 1) >> 1 : -(n >> 1));
             }
