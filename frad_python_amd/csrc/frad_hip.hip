@@ -252,6 +252,7 @@ int frad_plan_prepare(int32_t N, int32_t compute_f32) {
     const int l2 = log2_exact(N);
     if (l2 >= 7 && l2 <= 14) { Tables t; return get_tables(l2 - 1, compute_f32 != 0, t); }
     if (N < 1) return FRAD_E_INVALID;
+    { const int rc = mixed_prepare(N, unit_neg); if (rc != FRAD_OK) return rc; }
     if (!compute_f32) { const int rc = blue_prepare(N); if (rc != FRAD_OK) return rc; }
     DirectTable d; return get_direct(N, d);
 }
@@ -262,6 +263,7 @@ void frad_plan_clear(void) {
     for (auto& kv : g_direct) (void)hipFree(kv.second.ct);
     g_tables.clear(); g_direct.clear();
     blue_clear();
+    mixed_clear();
     crc_clear();
     p1_clear();
     wave_clear();
@@ -445,6 +447,11 @@ int p0_analogue_impl(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
             }
         }
     } else {
+        {                                                    // N = 2 r 2^p, r in {3, 5, 7}: mixed-radix FFT (frad_mixed.hip), float64 for every PCM type
+            const int r = launch_p0_fwd_mixed(lg, s, in, out, absmax, g, ai, ao, unit_neg);
+            if (r < 0) { if (r == FRAD_E_HIP) g_last_hip = mixed_last_hip_error(); return r; }
+            if (r == 1) return FRAD_OK;
+        }
         if (!f32) {                                          // any N in O(N log N): Bluestein over the power-of-two FFT
             const int r = launch_p0_fwd_blue(lg, s, in, out, absmax, g, ao);
             if (r < 0) { if (r == FRAD_E_HIP) g_last_hip = blue_last_hip_error(); return r; }
@@ -545,6 +552,11 @@ int p0_digital_impl(const void* payload, int64_t payload_stride, int64_t n_frame
             if (rc != FRAD_OK) return rc;
         }
     } else {
+        {
+            const int rm = launch_p0_inv_mixed(s, in, pcm_out, g, ai, unit_neg);
+            if (rm < 0) { if (rm == FRAD_E_HIP) g_last_hip = mixed_last_hip_error(); return rm; }
+            if (rm == 1) return FRAD_OK;
+        }
         const int r = launch_p0_inv_blue(s, in, pcm_out, g, ai);
         if (r < 0) { if (r == FRAD_E_HIP) g_last_hip = blue_last_hip_error(); return r; }
         if (r == 1) { HIPCHK(hipGetLastError()); return FRAD_OK; }

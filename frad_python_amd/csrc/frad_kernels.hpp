@@ -359,7 +359,7 @@ __device__ FRAD_NOINLINE void stage_in_pcm(const unsigned char* __restrict__ pcm
         const int chunks = (NC + EPC - 1) / EPC;      // NC * itemsize is a multiple of 16 here
         auto fetch = [&](int q, uint32_t (&w)[4]) {
             const int fl = q / chunks, ch = q - fl * chunks;
-            const unsigned char* src = pcm + (((f0 + fl) * g.frame_stride * C) << LG);
+            const unsigned char* src = pcm + ((frame_base(g, f0 + fl) * C) << LG);
             const int e0 = ch * EPC;
             if (e0 + EPC <= nv) load_words<4>(src + ((long long)e0 << LG), w);
             else {
@@ -409,7 +409,7 @@ __device__ FRAD_NOINLINE void stage_in_pcm(const unsigned char* __restrict__ pcm
         for (int q = threadIdx.x; q < nfl * NC; q += blockDim.x) {
             const int fl = q / NC, e = q - fl * NC;
             const int n = e / C, c = e - n * C;
-            const unsigned char* src = pcm + (((f0 + fl) * g.frame_stride * C) << LG);
+            const unsigned char* src = pcm + ((frame_base(g, f0 + fl) * C) << LG);
             const T v = e < nv ? cvt_pcm<T>(load_raw(src + ((long long)e << LG), LG), g.dtype, g.raw_be) : (T)0;
             xslot<T, SH>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n) = v;
         }
@@ -857,7 +857,7 @@ __device__ FRAD_NOINLINE void stage_in_pcm_group(const unsigned char* __restrict
     FRAD_DYN_SMEM(smem_base_);
     unsigned char* smem = smem_base_ + smem_off;
     const int N = g.N, C = g.C;
-    const unsigned char* src = pcm + ((f * g.frame_stride * C) << LG);
+    const unsigned char* src = pcm + ((frame_base(g, f) * C) << LG);
     const int total = N * cgn, TH = blockDim.x;
     int q0 = threadIdx.x;
     if (g.n_valid == N) {                                    // batches of 8 element loads in flight per lane, format resolved once

@@ -71,8 +71,15 @@ int launch_p0_inv_blue(hipStream_t s, const unsigned char* pay, double* out, Geo
 int blue_prepare(int N);
 void blue_clear();
 int blue_last_hip_error();
-// wave-autonomous kernels for N = 2048, C <= 2, 16/32/64-bit storage (frad_p0_wave.hip): 1 = launched, 0 = not applicable
+// mixed-radix kernels for N = 2 r 2^p, r in {3, 5, 7} (frad_mixed.hip): 1 = launched, 0 = not applicable, < 0 = FRAD_E_*
 typedef void (*unit_root_fn)(long long, long long, long double&, long double&);      // exp(-i pi p / q)
+int launch_p0_fwd_mixed(int lg, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* absmax, const Geom& g,
+                        int aligned_in, int aligned_out, unit_root_fn unit);
+int launch_p0_inv_mixed(hipStream_t s, const unsigned char* pay, double* out, const Geom& g, int aligned_in, unit_root_fn unit);
+int mixed_prepare(int N, unit_root_fn unit);
+void mixed_clear();
+int mixed_last_hip_error();
+// wave-autonomous kernels for N = 2048, C <= 2, 16/32/64-bit storage (frad_p0_wave.hip): 1 = launched, 0 = not applicable
 int launch_p0_fwd_wave(int lg, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* absmax, const Geom& g,
                        int aligned_in, int aligned_out, unit_root_fn unit);
 int launch_p0_inv_wave(hipStream_t s, const unsigned char* pay, double* out, const Geom& g, int aligned_in, int aligned_out,

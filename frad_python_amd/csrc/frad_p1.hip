@@ -13,6 +13,12 @@
 
 using namespace frad;
 
+namespace frad {
+int launch_p1_fwd_mixed(int lg, hipStream_t s, const unsigned char* pcm, int32_t* q, int32_t* tq, const Geom& g, const P1Tables& tb,
+                        int aligned_in, unit_root_fn unit);
+int launch_p1_inv_mixed(hipStream_t s, const int32_t* q, const int32_t* tq, double* out, const Geom& g, const P1Tables& tb, unit_root_fn unit);
+}
+
 namespace {
 
 // ref: fourier/tools/p1tools.py:4-9 (Hz), fourier/profiles.py:5 (rates), :14-23 (frame sizes)
@@ -272,6 +278,11 @@ int frad_p1_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
     } else {
         const size_t lds = 2 * (size_t)N * C * 8 + p1_scratch_bytes(C, N);
         if (n_frames > 0x7fffffffLL / C) return FRAD_E_UNSUPPORTED;
+        {                                                    // {160, 192, 224} x 2^n: mixed-radix FFT (frad_mixed.hip)
+            const int r = launch_p1_fwd_mixed(lg, s, in, q, tq, g, tb, ai, p1_unit_neg);
+            if (r < 0) { if (r == FRAD_E_HIP) g_last = mixed_last_hip_error(); return r; }
+            if (r == 1) return FRAD_OK;
+        }
         if (lds > kLds) {
             rc = global_p1_analogue(in, q, tq, g, tb, s);
             if (rc == FRAD_E_HIP) g_last = global_last_hip_error();
@@ -360,6 +371,11 @@ int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32
     } else {
         const size_t lds = 2 * (size_t)N * C * 8 + p1_scratch_bytes(C, N);
         if (n_frames > 0x7fffffffLL / C) return FRAD_E_UNSUPPORTED;
+        {
+            const int r = launch_p1_inv_mixed(s, q, tq, pcm_out, g, tb, p1_unit_neg);
+            if (r < 0) { if (r == FRAD_E_HIP) g_last = mixed_last_hip_error(); return r; }
+            if (r == 1) return FRAD_OK;
+        }
         if (lds > kLds) {
             rc = global_p1_digital(q, tq, pcm_out, g, tb, s);
             if (rc == FRAD_E_HIP) g_last = global_last_hip_error();

@@ -166,6 +166,31 @@ def test_p0_any_length(be, fmt):
                 assert np.max(np.abs(dec[f] - ref[f][1])) <= 16 * EPS64 * max(np.log2(N), 1) * max(1.0, np.max(np.abs(ref[f][1])))
 
 
+@pytest.mark.parametrize("fmt", ["s16le", "f32le"])
+def test_p0_mixed_radix_lengths(be, fmt):
+    """N = 2 r 2^p, r in {3, 5, 7}: the mixed-radix FFT kernels (frad_mixed.hip) -- a clip's last frame of config 3 (896) and
+    the lossless use of the compact family's sizes; same contract as every other profile-0 kernel."""
+    rng = np.random.default_rng(23)
+    shapes = _sizes(be, [(384, 2, 2), (896, 2, 2), (640, 3, 1), (2560, 1, 1)],
+                    [(384, 2, 3), (896, 2, 5), (640, 3, 2), (1536, 2, 2), (2560, 2, 2), (3584, 1, 2), (5120, 2, 2), (6144, 1, 1),
+                     (7168, 1, 2), (10240, 1, 1), (14336, 1, 1) if False else (1792, 4, 2)])
+    for (N, C, F) in shapes:
+        raw = synth.to_pcm(rng.uniform(-1, 1, (F * N, C)), fmt)
+        for bits in (16, 32, 64):
+            for le in (False, True):
+                ref = oracle_frames(fo, 0, raw, fmt, F, N, C, bits, le)
+                pay, am = be.analogue(0, raw, fmt, F, N, C, bits, le)
+                for f in range(F):
+                    gv, wv = payload_values(fo, pay[f], bits, le), payload_values(fo, ref[f][0], bits, le)
+                    eps = {16: 2.0 ** -10, 32: 2.0 ** -23, 64: 0}[bits] + (8 * EPS32 if fmt == "f32le" else 8 * EPS64) * np.log2(N)
+                    assert np.max(np.abs(gv - wv)) <= eps * np.max(np.abs(wv)) * 2, (N, C, bits)
+                    if fmt == "s16le" and bits == 32:
+                        assert check_p0_payload(pay[f], ref[f][0], bits, le, fmt, N) <= 2
+                dec = be.digital(0, np.stack([r[0] for r in ref]), F, N, C, bits, le)
+                for f in range(F):
+                    assert np.max(np.abs(dec[f] - ref[f][1])) <= 8 * EPS64 * np.log2(N) * max(1.0, np.max(np.abs(ref[f][1]))), (N, C, bits)
+
+
 def test_p0_frames_wider_than_a_cu(be):
     """Frames whose float64 channels exceed the 160 KiB LDS go through channel groups; with exactly two groups
     (cfg 4: N = 4096, C = 8) decode runs the whole-row two-pass kernel (k_p0_inv_grp2)."""

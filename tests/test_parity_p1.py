@@ -90,6 +90,27 @@ def test_p1_decode_of_frames_the_tables_do_not_hold(be, C):
         assert np.max(np.abs(dec[f] - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref))), f"frame {f}"
 
 
+@pytest.mark.parametrize("geom", [(640, 2, 32000), (896, 1, 44100), (1536, 2, 48000), (1792, 2, 48000), (3072, 1, 96000), (5120, 2, 44100),
+                                  (7168, 1, 48000), (6144, 1, 96000)])
+def test_p1_compact_sizes_through_the_mixed_radix_kernels(be, geom):
+    """{160, 192, 224} x 2^n (fourier/profiles.py:14-23) in O(N log N): K7 / K8 around the mixed-radix FFT (frad_mixed.hip)."""
+    N, C, srate = geom
+    if be.name == "emu" and N > 1792:
+        pytest.skip("emulator: covered by the smaller sizes")
+    F = 2
+    raw = synth.to_pcm(synth.harmonic_mix(F * N, C, srate, seed=N), "s16le")
+    dt = fo.pcm_dtype("s16le")
+    for loss in (0.553, 5.065):
+        q, tq = be.p1_analogue(raw, "s16le", F, N, C, 16, srate, loss)
+        for f in range(F):
+            wq, wt, aux = fo.p1_analogue_pre(fo.to_f64(raw[f * N:(f + 1) * N], dt), 16, srate, loss)
+            _check_ints(q[f].reshape(-1), wq, f"q N={N} f{f}")
+            _check_ints(tq[f].reshape(-1), wt, f"tq N={N} f{f}")
+            dec = be.p1_digital(wq.reshape(1, N, C).astype(np.int32), wt.reshape(1, 27, C).astype(np.int32), N, C, 16, srate)[0]
+            ref = fo.p1_digital_post(wq, wt, 2, C, srate, N)
+            assert np.max(np.abs(dec - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+
+
 def test_p1_short_frame_is_zero_padded(be):
     """flush: the last frame is shorter than the compact size and is padded (profile1.py:19)."""
     N, C, nv = 1024, 2, 900
