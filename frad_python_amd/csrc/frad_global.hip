@@ -163,6 +163,24 @@ int dct_bpr(int N) { return (N + 255) / 256; }
 dim3 dct_grid(int N, long long rows) { return dim3((unsigned)(dct_bpr(N) * rows)); }
 int stage_bpf(int N, int C) { const long long b = ((long long)N * C + 255) / 256; return (int)(b > 64 ? 64 : b); }
 
+// DCT of `rows` planar rows: O(N log N) through the mixed-radix kernels (frad_mixed.hip) when N = 2 r 2^p, else the dense product
+template <bool FWD>
+int rows_dct(const double* in, double* out, void* zw, const double* ct, int N, int C, long long rows, long long fstride, long long cstride,
+             long long ostride, hipStream_t s) {
+    if (zw != nullptr) {
+        const int r = global_dct_mixed(FWD, in, out, zw, N, C, rows, fstride, cstride, ostride, s, unit_root);
+        if (r != 0) return r < 0 ? r : FRAD_OK;
+    }
+    hipLaunchKernelGGL(k_g_dct<FWD>, dct_grid(N, rows), dim3(256), TN * 8, s, in, out, ct, N, C, fstride, cstride, ostride, dct_bpr(N));
+    return FRAD_OK;
+}
+bool mixed_length(int N) {                                   // N = 2 r 2^p, r in {3, 5, 7}, 6 <= p <= 13
+    if (N & 1) return false;
+    const int M = N / 2;
+    for (int r : {3, 5, 7}) if (M % r == 0) { const int P = M / r; if (P >= 64 && P <= 8192 && (P & (P - 1)) == 0) return true; }
+    return false;
+}
+
 }  // namespace
 
 int global_last_hip_error() { return g_glob_hip; }
@@ -174,15 +192,16 @@ int global_p0_analogue(const unsigned char* pcm, unsigned char* payload, double*
     DirectTable d; int rc = get_direct(N, d);
     if (rc != FRAD_OK) return rc;
     const long long chunk = frames_per_chunk(g.n_frames, N, C);
-    Ws xw(s), Xw(s);
+    Ws xw(s), Xw(s), zw(s);
     if ((rc = xw.get((size_t)chunk * N * C * 8)) != FRAD_OK || (rc = Xw.get((size_t)chunk * N * C * 8)) != FRAD_OK) return rc;
+    if (mixed_length(N) && (rc = zw.get((size_t)chunk * N * C * 8)) != FRAD_OK) return rc;
     for (long long f0 = 0; f0 < g.n_frames; f0 += chunk) {
         const long long nf = g.n_frames - f0 < chunk ? g.n_frames - f0 : chunk;
         Geom gs = g; gs.fpb = stage_bpf(N, C);
         hipLaunchKernelGGL(k_g_pcm_to_ws, dim3((unsigned)(gs.fpb * nf)), dim3(256), 0, s, pcm, static_cast<double*>(xw.p), gs, f0);
         // coefficient rows interleaved [frame][k][c]: the order profile 0 packs them in (freqs.T.ravel(), profile0.py:29)
-        hipLaunchKernelGGL(k_g_dct<true>, dct_grid(N, nf * C), dim3(256), TN * 8, s, static_cast<const double*>(xw.p), static_cast<double*>(Xw.p),
-                           d.ct, N, C, (long long)N * C, 1LL, (long long)C, dct_bpr(N));
+        rc = rows_dct<true>(static_cast<const double*>(xw.p), static_cast<double*>(Xw.p), zw.p, d.ct, N, C, nf * C, (long long)N * C, 1LL, (long long)C, s);
+        if (rc != FRAD_OK) return rc;
         GCHK(hipGetLastError());
         rc = frad_p4_analogue(Xw.p, FRAD_PCM_F64LE, nf, N, C, N, g.bits, flags & FRAD_LITTLE_ENDIAN, payload + f0 * g.payload_stride,
                               g.payload_stride, absmax ? absmax + f0 : nullptr, s);
@@ -197,8 +216,9 @@ int global_p0_digital(const unsigned char* payload, double* out, const Geom& g, 
     DirectTable d; int rc = get_direct(N, d);
     if (rc != FRAD_OK) return rc;
     const long long chunk = frames_per_chunk(g.n_frames, N, C);
-    Ws Xi(s), Xp(s);
+    Ws Xi(s), Xp(s), zw(s);
     if ((rc = Xi.get((size_t)chunk * N * C * 8)) != FRAD_OK || (rc = Xp.get((size_t)chunk * N * C * 8)) != FRAD_OK) return rc;
+    if (mixed_length(N) && (rc = zw.get((size_t)chunk * N * C * 8)) != FRAD_OK) return rc;
     for (long long f0 = 0; f0 < g.n_frames; f0 += chunk) {
         const long long nf = g.n_frames - f0 < chunk ? g.n_frames - f0 : chunk;
         rc = frad_p4_digital(payload + f0 * g.payload_stride, g.payload_stride, nf, N, C, g.bits, flags & FRAD_LITTLE_ENDIAN,
@@ -209,8 +229,8 @@ int global_p0_digital(const unsigned char* payload, double* out, const Geom& g, 
         Geom gi = g; gi.dtype = FRAD_PCM_F64LE; gi.raw_be = 0; gi.frame_stride = N; gi.n_valid = N; gi.fpb = stage_bpf(N, C);
         hipLaunchKernelGGL(k_g_pcm_to_ws, dim3((unsigned)(gi.fpb * nf)), dim3(256), 0, s, static_cast<const unsigned char*>(Xi.p),
                            static_cast<double*>(Xp.p), gi, 0LL);
-        hipLaunchKernelGGL(k_g_dct<false>, dct_grid(N, nf * C), dim3(256), TN * 8, s, static_cast<const double*>(Xp.p), out + f0 * (long long)N * C,
-                           d.ct, N, C, (long long)N * C, 1LL, (long long)C, dct_bpr(N));
+        rc = rows_dct<false>(static_cast<const double*>(Xp.p), out + f0 * (long long)N * C, zw.p, d.ct, N, C, nf * C, (long long)N * C, 1LL, (long long)C, s);
+        if (rc != FRAD_OK) return rc;
         GCHK(hipGetLastError());
     }
     return FRAD_OK;
@@ -221,15 +241,16 @@ int global_p1_analogue(const unsigned char* pcm, int32_t* q, int32_t* tq, const 
     DirectTable d; int rc = get_direct(N, d);
     if (rc != FRAD_OK) return rc;
     const long long chunk = frames_per_chunk(g.n_frames, N, C);
-    Ws xw(s), Xw(s);
+    Ws xw(s), Xw(s), zw(s);
     if ((rc = xw.get((size_t)chunk * N * C * 8)) != FRAD_OK || (rc = Xw.get((size_t)chunk * N * C * 8)) != FRAD_OK) return rc;
+    if (mixed_length(N) && (rc = zw.get((size_t)chunk * N * C * 8)) != FRAD_OK) return rc;
     const size_t lds = p1_scratch_bytes(1, N);
     for (long long f0 = 0; f0 < g.n_frames; f0 += chunk) {
         const long long nf = g.n_frames - f0 < chunk ? g.n_frames - f0 : chunk;
         Geom gs = g; gs.fpb = stage_bpf(N, C);
         hipLaunchKernelGGL(k_g_pcm_to_ws, dim3((unsigned)(gs.fpb * nf)), dim3(256), 0, s, pcm, static_cast<double*>(xw.p), gs, f0);
-        hipLaunchKernelGGL(k_g_dct<true>, dct_grid(N, nf * C), dim3(256), TN * 8, s, static_cast<const double*>(xw.p), static_cast<double*>(Xw.p),
-                           d.ct, N, C, (long long)N * C, (long long)N, 1LL, dct_bpr(N));                   // planar rows for the band sums
+        rc = rows_dct<true>(static_cast<const double*>(xw.p), static_cast<double*>(Xw.p), zw.p, d.ct, N, C, nf * C, (long long)N * C, (long long)N, 1LL, s);   // planar rows for the band sums
+        if (rc != FRAD_OK) return rc;
         hipLaunchKernelGGL(k_g_p1_quant, dim3((unsigned)(nf * C)), dim3(256), lds, s, static_cast<const double*>(Xw.p), q, tq, g, tb, f0);
         GCHK(hipGetLastError());
     }
@@ -241,14 +262,15 @@ int global_p1_digital(const int32_t* q, const int32_t* tq, double* out, const Ge
     DirectTable d; int rc = get_direct(N, d);
     if (rc != FRAD_OK) return rc;
     const long long chunk = frames_per_chunk(g.n_frames, N, C);
-    Ws Xw(s);
+    Ws Xw(s), zw(s);
     if ((rc = Xw.get((size_t)chunk * N * C * 8)) != FRAD_OK) return rc;
+    if (mixed_length(N) && (rc = zw.get((size_t)chunk * N * C * 8)) != FRAD_OK) return rc;
     const size_t lds = p1_scratch_bytes(1, N);
     for (long long f0 = 0; f0 < g.n_frames; f0 += chunk) {
         const long long nf = g.n_frames - f0 < chunk ? g.n_frames - f0 : chunk;
         hipLaunchKernelGGL(k_g_p1_dequant, dim3((unsigned)(nf * C)), dim3(256), lds, s, q, tq, static_cast<double*>(Xw.p), g, tb, f0);
-        hipLaunchKernelGGL(k_g_dct<false>, dct_grid(N, nf * C), dim3(256), TN * 8, s, static_cast<const double*>(Xw.p), out + f0 * (long long)N * C,
-                           d.ct, N, C, (long long)N * C, 1LL, (long long)C, dct_bpr(N));
+        rc = rows_dct<false>(static_cast<const double*>(Xw.p), out + f0 * (long long)N * C, zw.p, d.ct, N, C, nf * C, (long long)N * C, 1LL, (long long)C, s);
+        if (rc != FRAD_OK) return rc;
         GCHK(hipGetLastError());
     }
     return FRAD_OK;

@@ -85,6 +85,7 @@ int build_tables(int log2m, Tables& out) {
 
 }  // namespace
 namespace frad {
+void unit_root(long long p, long long q, long double& re, long double& im) { unit_neg(p, q, re, im); }
 int get_tables(int log2m, bool f32, Tables& out) {
     int dev = 0; HIPCHK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_mu);

@@ -77,6 +77,10 @@ int launch_p0_fwd_mixed(int lg, hipStream_t s, const unsigned char* pcm, unsigne
                         int aligned_in, int aligned_out, unit_root_fn unit);
 int launch_p0_inv_mixed(hipStream_t s, const unsigned char* pay, double* out, const Geom& g, int aligned_in, unit_root_fn unit);
 int mixed_prepare(int N, unit_root_fn unit);
+// the DCT of planar float64 rows in HBM through a complex workspace of rows * N / 2 slots (frames wider than a CU): 1 / 0 / < 0
+int global_dct_mixed(bool fwd, const double* in, double* out, void* zw, int N, int C, long long rows, long long fstride, long long cstride,
+                     long long ostride, hipStream_t s, unit_root_fn unit);
+void unit_root(long long p, long long q, long double& re, long double& im);     // exp(-i pi p / q), q even (frad_hip.hip)
 void mixed_clear();
 int mixed_last_hip_error();
 // wave-autonomous kernels for N = 2048, C <= 2, 16/32/64-bit storage (frad_p0_wave.hip): 1 = launched, 0 = not applicable

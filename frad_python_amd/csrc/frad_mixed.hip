@@ -294,6 +294,133 @@ __global__ void __launch_bounds__(256) k_p1_inv_mixed(const int32_t* __restrict_
     }
 }
 
+// ---- frames wider than a CU: the same decomposition through an HBM workspace (frad_global.hip's rows) -------------------
+// zw: complex [rows][M], a row = r sub-buffers of P points (decimated layout on the way in, blocked -- Z[k] in buffer k / P --
+// after the radix pass).  Three launches per direction: pack (or the inverse pair step), the P-point sub-FFTs (one block per
+// sub-buffer, LDS-resident), radix pass fused with the pair step (or with the un-permutation).
+__global__ void __launch_bounds__(256) k_gm_pack(const double* __restrict__ xin, cx<double>* __restrict__ zw, int N, int r, int log2p) {
+    const int M = N / 2, H = M / 2;
+    const long long row = blockIdx.y;
+    const double* x = xin + row * (long long)N;
+    cx<double>* z = zw + row * (long long)M;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < H; q += gridDim.x * blockDim.x) {
+        const int m0 = q, m1 = M - 1 - q;
+        z[((long long)(m0 % r) << log2p) + m0 / r] = cx<double>{x[4 * q], x[4 * q + 2]};
+        z[((long long)(m1 % r) << log2p) + m1 / r] = cx<double>{x[4 * q + 3], x[4 * q + 1]};
+    }
+}
+
+template <int L2, bool INV>
+__global__ void __launch_bounds__(Plan<L2>::TEAM) k_gm_sub(cx<double>* __restrict__ zw, const cx<double>* __restrict__ twp) {
+    constexpr int P = 1 << L2, TEAM = Plan<L2>::TEAM, SH = Plan<L2>::SH;
+    FRAD_DYN_SMEM(smem);
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);
+    cx<double>* g = zw + ((long long)blockIdx.x << L2);
+    for (int i = threadIdx.x; i < P; i += TEAM) buf[phys<double, SH>(i)] = g[i];
+    __syncthreads();
+    int t = threadIdx.x;
+    fft_team<double, L2, INV>(buf, t, twp);
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += TEAM) g[i] = buf[phys<double, SH>(i)];
+}
+
+// forward: columns k1 and P - k1 of a row -> twiddle + radix-r -> the r pairs (k, M - k) they hold -> pair step -> X
+__global__ void __launch_bounds__(256) k_gm_radix_post(const cx<double>* __restrict__ zw, double* __restrict__ out, MixedTab mt, int N, int C,
+                                                       long long fstride, long long cstride, long long ostride) {
+    const int r = mt.r, log2p = mt.log2p, P = 1 << log2p, M = N / 2, H = M / 2;
+    const long long row = blockIdx.y;
+    const cx<double>* z = zw + row * (long long)M;
+    double* o = out + (row / C) * fstride + (row % C) * cstride;
+    const double sc = 1.0 / (double)(2 * N), sc2 = K<double>::s2 / (double)(2 * N);
+    for (int k1 = blockIdx.x * blockDim.x + threadIdx.x; k1 <= P / 2; k1 += gridDim.x * blockDim.x) {
+        const int k1m = (P - k1) & (P - 1);
+        cx<double> ya[7], yb[7];
+#pragma unroll
+        for (int b = 0; b < 7; ++b) if (b < r) {
+            ya[b] = z[((long long)b << log2p) + k1]; yb[b] = z[((long long)b << log2p) + k1m];
+            if (b > 0) { ya[b] = cmul(ya[b], mt.tw2[(b - 1) * P + k1]); yb[b] = cmul(yb[b], mt.tw2[(b - 1) * P + k1m]); }
+        }
+        if (r == 3) { dft_small<3, false>(ya); dft_small<3, false>(yb); }
+        else if (r == 5) { dft_small<5, false>(ya); dft_small<5, false>(yb); }
+        else { dft_small<7, false>(ya); dft_small<7, false>(yb); }
+        // ya[k2] = Z[k1 + P k2], yb[k2] = Z[k1m + P k2]; partner of k = k1 + P k2 is M - k = k1m + P (r - 1 - k2) (k1 > 0) or P (r - k2) (k1 = 0)
+#pragma unroll
+        for (int k2 = 0; k2 < 7; ++k2) if (k2 < r) {
+            const int k = k1 + (k2 << log2p);
+            if (k > H) continue;                              // each pair once: k in [0, M/2]
+            cx<double> zm;
+            if (k1 == 0) zm = k2 == 0 ? ya[0] : ya[r - k2]; else zm = yb[r - 1 - k2];
+            const cx<double> zk = ya[k2], zp = conj(zm);
+            const cx<double> p = cmul(zk + zp, mt.post[2 * k]), q = cmul(zk - zp, mt.post[2 * k + 1]);
+            const cx<double> S = p + q, D = p - q;
+            o[(long long)k * ostride] = S.x * sc;
+            if (k > 0) o[(long long)(N - k) * ostride] = -S.y * sc;
+            if (k < H) {
+                o[(long long)(M - k) * ostride] = (D.x - D.y) * sc2;
+                if (k > 0) o[(long long)(M + k) * ostride] = (D.x + D.y) * sc2;
+            }
+        }
+        // the pairs whose smaller member sits in column k1m (k = k1m + P k2 <= M/2), unless the two columns coincide
+        if (k1m != k1) {
+#pragma unroll
+            for (int k2 = 0; k2 < 7; ++k2) if (k2 < r) {
+                const int k = k1m + (k2 << log2p);
+                if (k > H) continue;
+                const cx<double> zk = yb[k2], zp = conj(ya[r - 1 - k2]);
+                const cx<double> p = cmul(zk + zp, mt.post[2 * k]), q = cmul(zk - zp, mt.post[2 * k + 1]);
+                const cx<double> S = p + q, D = p - q;
+                o[(long long)k * ostride] = S.x * sc;
+                o[(long long)(N - k) * ostride] = -S.y * sc;
+                if (k < H) {
+                    o[(long long)(M - k) * ostride] = (D.x - D.y) * sc2;
+                    o[(long long)(M + k) * ostride] = (D.x + D.y) * sc2;
+                }
+            }
+        }
+    }
+}
+
+// inverse, step 1: X row (planar) -> Z' in the decimated layout (frad_fft.hpp dct_pre_inverse)
+__global__ void __launch_bounds__(256) k_gm_pre_inverse(const double* __restrict__ xin, cx<double>* __restrict__ zw, MixedTab mt, int N) {
+    const int r = mt.r, log2p = mt.log2p, M = N / 2, H = M / 2;
+    const long long row = blockIdx.y;
+    const double* X = xin + row * (long long)N;
+    cx<double>* z = zw + row * (long long)M;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k <= H; k += gridDim.x * blockDim.x) {
+        const double xk = X[k], xnk = k > 0 ? X[N - k] : 0.0;
+        const double a = X[M - k], b = X[k > 0 ? M + k : M];
+        const cx<double> u = {xk, -xnk};
+        const cx<double> s = {(a + b) * K<double>::s2, (b - a) * K<double>::s2};
+        const cx<double> A = cmul(u + s, conj(mt.post[2 * k])), B = cmul(u - s, conj(mt.post[2 * k + 1]));
+        z[((long long)(k % r) << log2p) + k / r] = A + B;
+        if (k > 0 && k < H) { const int m = M - k; z[((long long)(m % r) << log2p) + m / r] = conj(A - B); }
+    }
+}
+
+// inverse, step 3: conjugate twiddle + radix-r -> z[m1 + P m2] -> Makhoul's permutation undone -> out (strided)
+__global__ void __launch_bounds__(256) k_gm_radix_unpack(const cx<double>* __restrict__ zw, double* __restrict__ out, MixedTab mt, int N, int C,
+                                                         long long fstride, long long cstride, long long ostride) {
+    const int r = mt.r, log2p = mt.log2p, P = 1 << log2p, M = N / 2, H = M / 2;
+    const long long row = blockIdx.y;
+    const cx<double>* z = zw + row * (long long)M;
+    double* o = out + (row / C) * fstride + (row % C) * cstride;
+    for (int k1 = blockIdx.x * blockDim.x + threadIdx.x; k1 < P; k1 += gridDim.x * blockDim.x) {
+        cx<double> y[7];
+#pragma unroll
+        for (int b = 0; b < 7; ++b) if (b < r) {
+            y[b] = z[((long long)b << log2p) + k1];
+            if (b > 0) y[b] = cmul(y[b], conj(mt.tw2[(b - 1) * P + k1]));
+        }
+        if (r == 3) dft_small<3, true>(y); else if (r == 5) dft_small<5, true>(y); else dft_small<7, true>(y);
+#pragma unroll
+        for (int m2 = 0; m2 < 7; ++m2) if (m2 < r) {
+            const int m = k1 + (m2 << log2p);
+            if (m < H) { o[(long long)(4 * m) * ostride] = y[m2].x; o[(long long)(4 * m + 2) * ostride] = y[m2].y; }
+            else { const int q = M - 1 - m; o[(long long)(4 * q + 3) * ostride] = y[m2].x; o[(long long)(4 * q + 1) * ostride] = y[m2].y; }
+        }
+    }
+}
+
 // ---- host: geometry, tables ------------------------------------------------------------------------------------------
 constexpr size_t kLds = 160 * 1024;
 thread_local int g_mixed_hip = 0;
@@ -301,7 +428,7 @@ std::mutex g_mixed_mu;
 struct MixedDev { cx<double>* tw2 = nullptr; cx<double>* post = nullptr; };
 std::map<std::pair<int, int>, MixedDev> g_mixed;             // (device, N)
 
-bool mixed_geometry(int N, int& r, int& log2p) {
+bool mixed_geometry(int N, int& r, int& log2p, int max_log2p = 10) {
     if (N < 2 * 3 * 64 || (N & 1)) return false;
     const int M = N / 2;
     for (int rr : {3, 5, 7}) {
@@ -309,16 +436,16 @@ bool mixed_geometry(int N, int& r, int& log2p) {
         const int P = M / rr;
         if (P & (P - 1)) continue;
         int l = 0; while ((1 << l) < P) ++l;
-        if (l < 6 || l > 10) continue;
+        if (l < 6 || l > max_log2p) continue;
         r = rr; log2p = l;
         return true;
     }
     return false;
 }
 
-int mixed_tables(int N, unit_root_fn unit, MixedTab& mt) {
+int mixed_tables(int N, unit_root_fn unit, MixedTab& mt, int max_log2p = 10) {
     int r = 0, log2p = 0;
-    if (!mixed_geometry(N, r, log2p)) return 0;
+    if (!mixed_geometry(N, r, log2p, max_log2p)) return 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return FRAD_E_HIP;
     Tables t;
@@ -433,6 +560,45 @@ int launch_p1_inv_mixed(hipStream_t s, const int32_t* q, const int32_t* tq, doub
     allow_lds(k_p1_inv_mixed<0>, lds);
     hipLaunchKernelGGL(k_p1_inv_mixed<0>, dim3((unsigned)g.n_frames), dim3(256), lds, s, q, tq, out, gg, tb, mt);
     MCHK(hipGetLastError());
+    return 1;
+}
+
+
+// The DCT of `rows` planar float64 rows (forward: x -> X, inverse: X -> x) through the workspace `zw` (rows * N / 2 complex);
+// element o of row r goes to out[(r / C) * fstride + (r % C) * cstride + o * ostride] as in k_g_dct (frad_global.hip).
+// 1 = done, 0 = N is not of this family, < 0 = FRAD_E_*
+int global_dct_mixed(bool fwd, const double* in, double* out, void* zw, int N, int C, long long rows, long long fstride, long long cstride,
+                     long long ostride, hipStream_t s, unit_root_fn unit) {
+    if (mixed_off() || rows > 65535) return 0;
+    MixedTab mt;
+    const int rc = mixed_tables(N, unit, mt, 13);
+    if (rc <= 0) return rc;
+    const int P = 1 << mt.log2p, M = N / 2;
+    cx<double>* z = static_cast<cx<double>*>(zw);
+    auto sub = [&](auto tag, auto inv) {
+        constexpr int L2 = decltype(tag)::value; constexpr bool INV = decltype(inv)::value;
+        allow_lds(k_gm_sub<L2, INV>, (size_t)16 << L2);
+        hipLaunchKernelGGL((k_gm_sub<L2, INV>), dim3((unsigned)(rows * mt.r)), dim3(Plan<L2>::TEAM), (size_t)16 << L2, s, z, mt.twp);
+    };
+    auto sub_any = [&](auto inv) {
+        switch (mt.log2p) {
+            case 6: sub(std::integral_constant<int, 6>{}, inv); break;   case 7: sub(std::integral_constant<int, 7>{}, inv); break;
+            case 8: sub(std::integral_constant<int, 8>{}, inv); break;   case 9: sub(std::integral_constant<int, 9>{}, inv); break;
+            case 10: sub(std::integral_constant<int, 10>{}, inv); break; case 11: sub(std::integral_constant<int, 11>{}, inv); break;
+            case 12: sub(std::integral_constant<int, 12>{}, inv); break; default: sub(std::integral_constant<int, 13>{}, inv); break;
+        }
+    };
+    auto bx = [](int items) { const int b = (items + 255) / 256; return (unsigned)(b < 1 ? 1 : b > 64 ? 64 : b); };
+    if (fwd) {
+        hipLaunchKernelGGL(k_gm_pack, dim3(bx(M / 2), (unsigned)rows), dim3(256), 0, s, in, z, N, mt.r, mt.log2p);
+        sub_any(std::false_type{});
+        hipLaunchKernelGGL(k_gm_radix_post, dim3(bx(P / 2 + 1), (unsigned)rows), dim3(256), 0, s, z, out, mt, N, C, fstride, cstride, ostride);
+    } else {
+        hipLaunchKernelGGL(k_gm_pre_inverse, dim3(bx(M / 2 + 1), (unsigned)rows), dim3(256), 0, s, in, z, mt, N);
+        sub_any(std::true_type{});
+        hipLaunchKernelGGL(k_gm_radix_unpack, dim3(bx(P), (unsigned)rows), dim3(256), 0, s, z, out, mt, N, C, fstride, cstride, ostride);
+    }
+    if (hipGetLastError() != hipSuccess) return FRAD_E_HIP;
     return 1;
 }
 

@@ -525,12 +525,11 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
     }
     // job s reads zk = (s < 8 ? E[s] : O[15 - s]) and zm = (s < 8 ? O[15 - s] : E[s]); lane 0 pairs E[s] with E[16 - s] and
     // O[15 - s] with O[s] instead (see wave_fwd_body), i.e. it wants E[8 .. 15] <- O[8 .. 15] and O[j] <- E[(j + 1) & 15], j >= 8
-    {
-        cx<T> e2[8], o2[8];
 #pragma unroll
-        for (int j = 8; j < 16; ++j) { e2[j - 8] = sel(O[j], E[j]); o2[j - 8] = sel(E[(j + 1) & 15], O[j]); }
-#pragma unroll
-        for (int j = 8; j < 16; ++j) { E[j] = e2[j - 8]; O[j] = o2[j - 8]; }
+    for (int j = 8; j < 16; ++j) {                            // ascending: E[j + 1] is still the old value when O[j] takes it
+        const cx<T> eo = E[j], oo = O[j];
+        E[j] = sel(oo, eo);
+        O[j] = sel(E[(j + 1) & 15], oo);
     }
     // ---- pair step, once: X[s][0..3] = X[k], X[M - k], X[M + k], X[N - k], k = wave_job_k(l, s); lane 0 of slot 0 (k = 0)
     //      carries X[0], X[512], X[M], X[1536] (the self-paired bins take the places of the two bins it does not have)

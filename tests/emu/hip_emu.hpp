@@ -48,13 +48,14 @@ inline unsigned char* smem_base() {
     return reinterpret_cast<unsigned char*>((p + 15) & ~uintptr_t(15));
 }
 template <typename F> void launch(dim3 grid, dim3 block, size_t lds, F&& body) {
+    for (unsigned by = 0; by < grid.y; ++by)
     for (unsigned bx = 0; bx < grid.x; ++bx) {
         Block b(block.x, lds);
         std::vector<std::thread> th;
         th.reserve(block.x);
         for (unsigned tx = 0; tx < block.x; ++tx)
             th.emplace_back([&, tx] {
-                blk = &b; t_idx = dim3(tx); b_idx = dim3(bx); b_dim = block; g_dim = grid;
+                blk = &b; t_idx = dim3(tx); b_idx = dim3(bx, by); b_dim = block; g_dim = grid;
                 body();
             });
         for (auto& t : th) t.join();

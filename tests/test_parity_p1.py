@@ -190,6 +190,26 @@ def test_p1_frames_wider_than_a_cu(be, geom, g6):
     assert np.max(np.abs(dec - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
 
 
+@pytest.mark.parametrize("geom", [(10240, 2, 48000), (12288, 3, 44100), (20480, 1, 96000), (24576, 1, 96000), (28672, 2, 48000)])
+def test_p1_widest_compact_sizes_in_n_log_n(be, geom):
+    """The compact sizes beyond a CU's LDS (up to 28 672 = 7 x 4096 samples) through the HBM workspaces with the mixed-radix
+    FFT (frad_mixed.hip k_gm_*) instead of the dense cosine product; oracle = the reference's arithmetic (scipy)."""
+    N, C, srate = geom
+    if be.name == "emu" and N > 10240:
+        pytest.skip("emulator: one wide geometry is enough")
+    F = 2
+    raw = synth.to_pcm(synth.harmonic_mix(F * N, C, srate, seed=N + C), "s16le")
+    dt = fo.pcm_dtype("s16le")
+    q, tq = be.p1_analogue(raw, "s16le", F, N, C, 16, srate, 0.553)
+    for f in range(F):
+        wq, wt, aux = fo.p1_analogue_pre(fo.to_f64(raw[f * N:(f + 1) * N], dt), 16, srate, 0.553)
+        _check_ints(q[f].reshape(-1), wq, f"q N={N} f{f}")
+        _check_ints(tq[f].reshape(-1), wt, f"tq N={N} f{f}")
+        dec = be.p1_digital(wq.reshape(1, N, C).astype(np.int32), wt.reshape(1, 27, C).astype(np.int32), N, C, 16, srate)[0]
+        ref = fo.p1_digital_post(wq, wt, 2, C, srate, N)
+        assert np.max(np.abs(dec - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Exp-Golomb-Rice stage on the device (SURVEY 8f #2; p1tools.py:46-74, profile1.py:43-45, 59-64): bit-exact, no tolerance
 # ---------------------------------------------------------------------------------------------------------------------
