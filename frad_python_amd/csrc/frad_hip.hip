@@ -437,7 +437,13 @@ int p0_analogue_impl(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
         }
         if (c.cg == C && ao && C <= 2 && ((long long)N * C) % 32 == 0) g.cc_fast = C;
         dim3 grid((unsigned)((n_frames + c.fpb - 1) / c.fpb));
-        if (!launch_p0_fwd_pers(f32, lg, c, s, in, out, absmax, tb, g, ao)) {
+        bool taken = false;
+        if (f32 && c.log2m == 11 && C == 8 && c.cg == C) {      // BASELINE config 4's geometry: two half-frame blocks per frame
+            if (absmax) HIPCHK(hipMemsetAsync(absmax, 0, sizeof(double) * (size_t)n_frames, s));   // atomicMax target
+            taken = launch_p0_fwd_half32(lg, c, s, in, out, absmax, tb, g, ai, ao) != 0;
+        }
+        if (taken) {
+        } else if (!launch_p0_fwd_pers(f32, lg, c, s, in, out, absmax, tb, g, ao)) {
             if (absmax) HIPCHK(hipMemsetAsync(absmax, 0, sizeof(double) * (size_t)n_frames, s));   // atomicMax target
             if (!f32 && c.cg < C && launch_p0_fwd_grp2(lg, c, s, in, out, absmax, tb, g, ai, ao)) {
                 // two channel groups with whole-row I/O took it (frad_p0_fwd_grp2.hip)

@@ -62,6 +62,9 @@ int launch_p0_inv_pers(const FastCfg& c, hipStream_t s, const unsigned char* pay
 int launch_p0_fwd_grp2(int lg, const FastCfg& c, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* absmax,
                        const Tables& tb, const Geom& g, int aligned_in, int aligned_out);
 int launch_p0_inv_grp2(const FastCfg& c, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb, const Geom& g);
+// float32 PCM, 8 channels at N = 4096: two co-resident half-frame blocks, one float32 pass each (frad_p0_fwd_half32.hip): 1 = launched
+int launch_p0_fwd_half32(int lg, const FastCfg& c, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* absmax,
+                         const Tables& tb, const Geom& g, int aligned_in, int aligned_out);
 
 
 // Bluestein kernels for frame lengths that are not a power of two (frad_p0_blue.hip): 1 = launched,
