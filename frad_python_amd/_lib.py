@@ -42,6 +42,7 @@ SYMBOLS = {
     "frad_p1_digital": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "frad_crc32_frames": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "frad_p1_overlap_add": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "frad_p1_overlap_add_pcm": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_int32, c_uint32, c_void_p, c_void_p, c_void_p]),
     "frad_p1_golomb_bound": (c_size_t, [c_int32, c_int32]),
     "frad_p1_golomb_encode": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
     "frad_rows_compact": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
@@ -183,6 +184,9 @@ class FradLib:
 
     def bench_copy(self, src, dst, nbytes, stream=0):
         self._check(self.dll.frad_bench_copy(src, dst, nbytes, stream))
+
+    def p1_overlap_add_pcm(self, frames, n_frames, N, C, ratio, prev_tail, out_dtype, out, next_tail, stream=0, flags=FRAD_RAW_BE_INTS):
+        self._check(self.dll.frad_p1_overlap_add_pcm(frames, n_frames, N, C, ratio, prev_tail, out_dtype, flags, out, next_tail, stream))
 
     def p1_overlap_add(self, frames, n_frames, N, C, ratio, prev_tail, out, next_tail, stream=0):
         self._check(self.dll.frad_p1_overlap_add(frames, n_frames, N, C, ratio, prev_tail, out, next_tail, stream))

@@ -143,6 +143,25 @@ class HipBridge:
         q, tq, status = self.core.p1_golomb_decode_batch(flat, t.from_numpy(off).to(self.device), N, C)
         return self.core.p1_digital_batch(q, tq, N, C, bits, srate).cpu().numpy()
 
+    def p1_decode_run(self, bodies: list, N, C, bits, srate, ratio, prev_tail, out_format=None):
+        """A run of overlapped compact frames, whole on the device: Golomb decode, K8, the Hann cross-fade against
+        ``prev_tail`` (decoder.py:28-46) and -- with ``out_format`` -- the output conversion in the same pass.  One upload
+        of the inflated bodies, one download of the finished PCM ``[n_frames * cut, C]`` and of the new tail (float64)."""
+        from .backend.pcmformat import ff_format_to_numpy_type
+        t = self.torch
+        off = np.zeros(len(bodies) + 1, np.int64)
+        np.cumsum([len(b) for b in bodies], out=off[1:])
+        flat = self._up(b"".join(bodies) + bytes(8))
+        q, tq, status = self.core.p1_golomb_decode_batch(flat, t.from_numpy(off).to(self.device), N, C)
+        frames = self.core.p1_digital_batch(q, tq, N, C, bits, srate)
+        pt = t.from_numpy(np.ascontiguousarray(prev_tail)).to(self.device) if prev_tail is not None else None
+        out, nxt = self.core.p1_overlap_add(frames, ratio, pt, out_format=out_format)
+        if out.dtype == t.uint8:
+            pcm = np.frombuffer(out.cpu().numpy().tobytes(), ff_format_to_numpy_type(out_format)).reshape(-1, C)
+        else:
+            pcm = out.cpu().numpy().reshape(-1, C)
+        return pcm, nxt.cpu().numpy()
+
     def p1_decode(self, q: np.ndarray, tq: np.ndarray, N, C, bits, srate) -> np.ndarray:
         t = self.torch
         return self.core.p1_digital_batch(t.from_numpy(np.ascontiguousarray(q, np.int32)).to(self.device),

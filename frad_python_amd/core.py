@@ -346,22 +346,28 @@ def p1_digital_batch(q: torch.Tensor, tq: torch.Tensor, N: int, C: int, bits: in
     return out
 
 
-def p1_overlap_add(frames: torch.Tensor, overlap_ratio: int, prev_tail: torch.Tensor | None = None):
+def p1_overlap_add(frames: torch.Tensor, overlap_ratio: int, prev_tail: torch.Tensor | None = None, out_format: str | None = None):
     """The decoder's Hann cross-fade over consecutive decoded frames (decoder.py:28-46).
 
     ``frames`` float64 [n_frames, N, C]; returns ``(out [n_frames, cut, C], next_tail [N - cut, C])``
-    with cut = N*(ratio-1)//ratio; ``prev_tail`` is the previous batch's ``next_tail`` (or None)."""
+    with cut = N*(ratio-1)//ratio; ``prev_tail`` is the previous batch's ``next_tail`` (or None).  ``out_format``: the
+    caller's ``from_f64(...).astype(fmt)`` (src/decoder.py:23) applied in the same pass -- ``out`` is then a uint8 tensor
+    holding ``[n_frames, cut, C]`` elements of that PCM format (frad_p1_overlap_add_pcm); the tail stays float64."""
     _require_cuda(frames, "frames")
     n_frames, N, C = frames.shape
     cut = N * (overlap_ratio - 1) // overlap_ratio
-    out = torch.empty((n_frames, cut, C), dtype=torch.float64, device=frames.device)
     nxt = torch.empty((N - cut, C), dtype=torch.float64, device=frames.device)
     if prev_tail is not None:
         _require_cuda(prev_tail, "prev_tail")
         if tuple(prev_tail.shape) != (N - cut, C):
             raise ValueError("prev_tail must be [N - cut, C]")
+    pt = prev_tail.data_ptr() if prev_tail is not None else 0
     with torch.cuda.device(frames.device):
-        _lib.load().p1_overlap_add(frames.data_ptr(), n_frames, N, C, overlap_ratio,
-                                   prev_tail.data_ptr() if prev_tail is not None else 0, out.data_ptr(), nxt.data_ptr(),
-                                   _stream_ptr())
+        if out_format is not None and out_format not in ("f64le",):
+            code = pcm_dtype_code(out_format)
+            out = torch.empty(n_frames * cut * C * itemsize_of(code) + 16, dtype=torch.uint8, device=frames.device)[:n_frames * cut * C * itemsize_of(code)]
+            _lib.load().p1_overlap_add_pcm(frames.data_ptr(), n_frames, N, C, overlap_ratio, pt, code, out.data_ptr(), nxt.data_ptr(), _stream_ptr())
+        else:
+            out = torch.empty((n_frames, cut, C), dtype=torch.float64, device=frames.device)
+            _lib.load().p1_overlap_add(frames.data_ptr(), n_frames, N, C, overlap_ratio, pt, out.data_ptr(), nxt.data_ptr(), _stream_ptr())
     return out, nxt

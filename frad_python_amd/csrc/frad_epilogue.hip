@@ -10,6 +10,7 @@
 //   k_from_f64        float64 [n] -> any of the 20 PCM formats; fused into the profile-4 unpack (k_p4_unpack_pcm).
 //   frad_asfh_scan    host code: walks a FrAD byte stream once and fills a table of frames (tools/asfh.py:98-134,
 //                     decoder.py:82-106) so that the Python decoder no longer parses headers frame by frame.
+#include "frad_p1.hpp"
 #include "frad_launch.hpp"
 #include "../../include/frad_hip.h"
 
@@ -67,6 +68,44 @@ __global__ void __launch_bounds__(256) k_from_f64(const unsigned char* __restric
             for (int e = 0; e < EPT; ++e) if (i0 + e < n) store_elem<LGS>(out + ((i0 + e) << LGS), b[e]);
         }
     }
+}
+
+// the decoder's overlap-add (k_p1_ola) with the output conversion applied on the way out: one pass over the decoded frames
+// instead of two (decoder.py:28-46, then src/decoder.py:23 from_f64(...).astype(fmt))
+template <int KIND, int LGS>
+__global__ void __launch_bounds__(256) k_p1_ola_pcm(const double* __restrict__ frames, long long n_frames, int N, int C, int cut,
+                                                    const double* __restrict__ prev_tail, unsigned char* __restrict__ out,
+                                                    double* __restrict__ next_tail, int be, int raw_be) {
+    constexpr int EPT = 16 >> LGS;
+    const long long n = n_frames * (long long)cut * C;
+    const bool vec = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    for (long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * EPT; i0 < n; i0 += (long long)gridDim.x * blockDim.x * EPT) {
+        u64 b[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const double x = i0 + e < n ? p1_ola_value(frames, prev_tail, N, C, cut, i0 + e) : 0.0;
+            b[e] = from_f64_bits<KIND, LGS>(x, raw_be != 0 && be);
+            if (be) b[e] = swap_elem<LGS>(b[e]);
+        }
+        if (vec && i0 + EPT <= n) {
+            v4u q = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                if constexpr (LGS == 3) { q[2 * e] = (uint32_t)b[e]; q[2 * e + 1] = (uint32_t)(b[e] >> 32); }
+                else if constexpr (LGS == 2) q[e] = (uint32_t)b[e];
+                else if constexpr (LGS == 1) q[e >> 1] |= (uint32_t)b[e] << (16 * (e & 1));
+                else q[e >> 2] |= (uint32_t)b[e] << (8 * (e & 3));
+            }
+            FRAD_NT_STORE(q, FRAD_GPTR(v4u, out + (i0 << LGS)));
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) if (i0 + e < n) store_elem<LGS>(out + ((i0 + e) << LGS), b[e]);
+        }
+    }
+    const int L = N - cut;
+    if (next_tail != nullptr && n_frames > 0)
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)L * C; i += (long long)gridDim.x * blockDim.x)
+            next_tail[i] = frames[((n_frames - 1) * N + cut) * C + i];
 }
 
 template <int SRC>
@@ -194,6 +233,34 @@ int frad_p1_digital_pcm(const int32_t* q, const int32_t* tq, int64_t n_frames, i
     int rc = frad_p1_digital(q, tq, n_frames, N, C, bits, srate, static_cast<double*>(ws.p), stream);
     if (rc != FRAD_OK) return rc;
     return frad_from_f64(static_cast<const double*>(ws.p), (int64_t)n, out_dtype, flags, pcm_out, stream);
+}
+
+int frad_p1_overlap_add_pcm(const double* frames, int64_t n_frames, int32_t N, int32_t C, int32_t overlap_ratio, const double* prev_tail,
+                            int32_t out_dtype, uint32_t flags, void* ola_out, double* next_tail, void* stream) {
+    if (!valid_out_dtype(out_dtype)) return FRAD_E_INVALID;
+    if (out_dtype == FRAD_PCM_F64LE) return frad_p1_overlap_add(frames, n_frames, N, C, overlap_ratio, prev_tail, static_cast<double*>(ola_out), next_tail, stream);
+    if (n_frames < 0 || N < 1 || C < 1 || overlap_ratio < 2 || overlap_ratio > 256) return FRAD_E_INVALID;
+    if (n_frames == 0) return FRAD_OK;
+    if (!frames || !ola_out) return FRAD_E_INVALID;
+    const int cut = (int)((long long)N * (overlap_ratio - 1) / overlap_ratio);     // decoder.py:44
+    const int kind = out_dtype >> 3, lg = (out_dtype >> 1) & 3, be = out_dtype & 1, raw = (flags & FRAD_RAW_BE_INTS) ? 1 : 0;
+    const long long total = n_frames * (long long)cut * C, per_block = 256LL * (16 >> lg);
+    long long blocks = (total + per_block - 1) / per_block;
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) blocks = 1;
+    const dim3 grid((unsigned)blocks), blk(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned char* o = static_cast<unsigned char*>(ola_out);
+#define GO(K, L) hipLaunchKernelGGL((k_p1_ola_pcm<K, L>), grid, blk, 0, s, frames, (long long)n_frames, N, C, cut, prev_tail, o, next_tail, be, raw)
+    switch (kind * 4 + lg) {
+        case 0: GO(0, 0); break; case 1: GO(0, 1); break; case 2: GO(0, 2); break; case 3: GO(0, 3); break;
+        case 4: GO(1, 0); break; case 5: GO(1, 1); break; case 6: GO(1, 2); break; case 7: GO(1, 3); break;
+        case 9: GO(2, 1); break; case 10: GO(2, 2); break; case 11: GO(2, 3); break;
+        default: return FRAD_E_INVALID;
+    }
+#undef GO
+    EPICHK(hipGetLastError());
+    return FRAD_OK;
 }
 
 // ---- native frame-header scan (host code, no device involved) --------------------------------------------------------

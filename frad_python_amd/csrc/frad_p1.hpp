@@ -348,29 +348,34 @@ __global__ void __launch_bounds__(256) k_p1_inv_direct(const int32_t* __restrict
 // R8: decoder overlap-add over a batch of consecutive frames (decoder.py:28-46).  Frame i keeps
 // rows [0, cut) -- its first L = N - cut rows cross-faded with frame i-1's tail -- and hands its
 // own tail [cut, N) to frame i+1.  out: [n_frames, cut, C]; next_tail: [L, C].
+// element i of the overlap-added output [n_frames, cut, C] (decoder.py:31-38, backend/__init__.py:3)
+__device__ __forceinline__ double p1_ola_value(const double* __restrict__ frames, const double* __restrict__ prev_tail, int N, int C, int cut, long long i) {
+    const int L = N - cut;
+    const double pi = 3.141592653589793;
+    const long long f = i / ((long long)cut * C);
+    const int r = (int)(i - f * (long long)cut * C), n = r / C, c = r - n * C;
+    double v = frames[(f * N + n) * C + c];
+    if (n < L) {
+        const double* tail = f > 0 ? frames + ((f - 1) * N + cut) * C : prev_tail;
+        if (tail != nullptr) {
+            // hanning_in_overlap (backend/__init__.py:3): w[i] = 0.5 (1 - cos(pi (i+1) / (L+1)))
+            const double w_in = 0.5 * (1.0 - cos(pi * (double)(n + 1) / (double)(L + 1)));
+            const double w_out = 0.5 * (1.0 - cos(pi * (double)(L - n) / (double)(L + 1)));
+            v = v * w_in;
+            v = v + tail[(long long)n * C + c] * w_out;
+        }
+    }
+    return v;
+}
+
 template <int UNUSED>
 __global__ void __launch_bounds__(256) k_p1_ola(const double* __restrict__ frames, long long n_frames, int N, int C, int cut,
                                                 const double* __restrict__ prev_tail, double* __restrict__ out,
                                                 double* __restrict__ next_tail) {
     const int L = N - cut;
     const long long total = n_frames * (long long)cut * C;
-    const double pi = 3.141592653589793;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long f = i / ((long long)cut * C);
-        const int r = (int)(i - f * (long long)cut * C), n = r / C, c = r - n * C;
-        double v = frames[(f * N + n) * C + c];
-        if (n < L) {
-            const double* tail = f > 0 ? frames + ((f - 1) * N + cut) * C : prev_tail;
-            if (tail != nullptr) {
-                // hanning_in_overlap (backend/__init__.py:3): w[i] = 0.5 (1 - cos(pi (i+1) / (L+1)))
-                const double w_in = 0.5 * (1.0 - cos(pi * (double)(n + 1) / (double)(L + 1)));
-                const double w_out = 0.5 * (1.0 - cos(pi * (double)(L - n) / (double)(L + 1)));
-                v = v * w_in;
-                v = v + tail[(long long)n * C + c] * w_out;
-            }
-        }
-        out[i] = v;
-    }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        out[i] = p1_ola_value(frames, prev_tail, N, C, cut, i);
     if (next_tail != nullptr && n_frames > 0)
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)L * C; i += (long long)gridDim.x * blockDim.x)
             next_tail[i] = frames[((n_frames - 1) * N + cut) * C + i];

@@ -118,6 +118,14 @@ class Decoder:
             bodies = _map_zlib(inflate, payloads)                  # runs of frames per pool task
             bad = [i for i, b in enumerate(bodies) if b is None]
             bodies = [b if b is not None else b"" for b in bodies]
+            fused = getattr(self.bridge, "p1_decode_run", None)
+            L = fsize - fsize * (ratio - 1) // ratio if ratio else 0
+            if fused is not None and ratio != 0 and (not self.overlap_fragment.size or self.overlap_fragment.shape == (L, channels)):
+                # the whole run on the device: Golomb decode, K8, the cross-fade and the output conversion; an undecodable frame
+                # is an empty body = all-zero integers = a frame of zeros (profile1.py:59-60) before the cross-fade, as in the reference
+                prev = self.overlap_fragment if self.overlap_fragment.size else None
+                pcm, self.overlap_fragment = fused(bodies, fsize, channels, bits, srate, ratio, prev, self.out_format)
+                return [pcm]
             pcm = self.bridge.p1_decode_bodies(bodies, fsize, channels, bits, srate)
             for i in bad:
                 pcm[i] = 0.0

@@ -203,6 +203,10 @@ int frad_p0_digital_pcm(const void* payload, int64_t payload_stride, int64_t n_f
                         uint32_t flags, int32_t out_dtype, void* pcm_out, void* stream);
 int frad_p4_digital_pcm(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C, int32_t bits,
                         uint32_t flags, int32_t out_dtype, void* pcm_out, void* stream);
+/* frad_p1_overlap_add_pcm == frad_p1_overlap_add with that conversion applied on the way out: ola_out [n_frames, cut, C] of
+ * out_dtype in one pass over the decoded frames (next_tail stays float64: it is the next batch's input).            */
+int frad_p1_overlap_add_pcm(const double* frames, int64_t n_frames, int32_t N, int32_t C, int32_t overlap_ratio, const double* prev_tail,
+                            int32_t out_dtype, uint32_t flags, void* ola_out, double* next_tail, void* stream);
 int frad_p1_digital_pcm(const int32_t* q, const int32_t* tq, int64_t n_frames, int32_t N, int32_t C, int32_t bits,
                         int32_t srate, int32_t out_dtype, uint32_t flags, void* pcm_out, void* stream);
 

@@ -158,6 +158,17 @@ class EmuBackend:
         self.lib.p1_overlap_add(fr.ctypes.data, F, N, C, ratio, pt.ctypes.data if pt is not None else 0, out.ctypes.data, nxt.ctypes.data)
         return out, nxt
 
+    def p1_ola_pcm(self, frames, ratio, fmt, prev_tail=None):
+        from frad_python_amd.backend.pcmformat import pcm_dtype_code, ff_format_to_numpy_type
+        F, N, C = frames.shape
+        cut = N * (ratio - 1) // ratio
+        dt = ff_format_to_numpy_type(fmt)
+        fr = np.ascontiguousarray(frames)
+        out = np.zeros(F * cut * C * dt.itemsize + 16, np.uint8); nxt = np.zeros((N - cut, C))
+        pt = np.ascontiguousarray(prev_tail) if prev_tail is not None else None
+        self.lib.p1_overlap_add_pcm(fr.ctypes.data, F, N, C, ratio, pt.ctypes.data if pt is not None else 0, pcm_dtype_code(fmt), out.ctypes.data, nxt.ctypes.data)
+        return np.frombuffer(out[:F * cut * C * dt.itemsize].tobytes(), dt).reshape(F, cut, C), nxt
+
 
 class GpuBackend:
     name = "gpu"
@@ -291,6 +302,16 @@ class GpuBackend:
         out, nxt = core.p1_overlap_add(t.from_numpy(np.ascontiguousarray(frames)).to(self.dev), ratio, pt)
         t.cuda.synchronize()
         return out.cpu().numpy(), nxt.cpu().numpy()
+
+    def p1_ola_pcm(self, frames, ratio, fmt, prev_tail=None):
+        from frad_python_amd import core
+        from frad_python_amd.backend.pcmformat import ff_format_to_numpy_type
+        t = self.torch
+        F, N, C = frames.shape
+        pt = t.from_numpy(np.ascontiguousarray(prev_tail)).to(self.dev) if prev_tail is not None else None
+        out, nxt = core.p1_overlap_add(t.from_numpy(np.ascontiguousarray(frames)).to(self.dev), ratio, pt, out_format=fmt)
+        t.cuda.synchronize()
+        return np.frombuffer(out.cpu().numpy().tobytes(), ff_format_to_numpy_type(fmt)).reshape(F, -1, C), nxt.cpu().numpy()
 
 
 def oracle_frames(fo, profile, raw, fmt, F, N, C, bits, le, frame_stride=None, raw_be=True):

@@ -86,6 +86,23 @@ def _scan_all(lib, data, chunked=None):
     return rows, pos, why
 
 
+@pytest.mark.parametrize("fmt", ["s16le", "s24le" if False else "s32le", "f32be", "u8", "s16be"])
+def test_overlap_add_with_output_format(be, fmt):
+    """frad_p1_overlap_add_pcm == from_f64(frad_p1_overlap_add(...)).astype(fmt) (decoder.py:28-46 then src/decoder.py:23), tail in float64"""
+    rng = np.random.default_rng(5)
+    F, N, C, ratio = 5, 640, 2, 16
+    frames = rng.uniform(-1.1, 1.1, (F, N, C))
+    prev = rng.uniform(-1, 1, (N - N * (ratio - 1) // ratio, C))
+    dt = fo.pcm_dtype(fmt)
+    for pt in (None, prev):
+        want, wtail = be.p1_ola(frames, ratio, pt)
+        got, gtail = be.p1_ola_pcm(frames, ratio, fmt, pt)
+        with np.errstate(all="ignore"):
+            ref = fo.from_f64(want, dt).astype(dt)
+        assert got.tobytes() == ref.tobytes(), fmt
+        assert np.array_equal(gtail, wtail)
+
+
 def test_native_header_scan_equals_the_reference_parser():
     """frad_asfh_scan (host C++, no device) against the oracle's restatement of ASFH.read on reference-generated streams
     (G3: lossless incl. ECC-free variants, profile 1 with force-flush headers), with garbage in front, a split signature

@@ -36,27 +36,42 @@ if stats:
         w.writerow(["(all other kernels: torch workload synthesis, overflow flag, memsets)", sum(int(r["Calls"]) for r in other),
                     sum(int(r["TotalDurationNs"]) for r in other), "", round(sum(float(r["Percentage"]) for r in other), 2), "", "", ""])
 
+# timed-steps-only durations of the two headline kernels from the kernel trace (bench.py: 5 cold-start steps, then the
+# pre-warm and warm-up steps, then the K timed ones, then the cold-rotation and yardstick sections)
+trace = one(f"prof_{tag}_trace/*/*_kernel_trace.csv")
+timed = {}
+try:
+    line = json.loads(open(os.path.join(src, f"prof_{tag}_bench_line.json")).read())
+    before = 5 + line["config"]["prewarm_steps"] + line["warmup"]
+    steps = line["steps"]
+except Exception:
+    line, before, steps = None, None, None
+if trace and before is not None:
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        if "k_p0_fwd_wave" in r["Kernel_Name"] or "k_p0_inv_wave" in r["Kernel_Name"]:
+            per[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    for k, v in per.items():
+        v.sort()
+        d = [x[1] for x in v[before:before + steps]]
+        if d:
+            timed[k] = {"launches": len(d), "avg_ns": sum(d) / len(d), "min_ns": min(d), "max_ns": max(d), "skipped_before": before}
+if stats and timed:
+    with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "a", newline="") as f:
+        w = csv.writer(f)
+        w.writerow([])
+        w.writerow(["# the same kernels over the K timed steps only (launches sorted by start time; cold-start, pre-warm and warm-up launches skipped)"])
+        w.writerow(["Name", "Launches", "AverageNs", "MinNs", "MaxNs", "LaunchesSkippedBefore"])
+        for k, t in timed.items():
+            w.writerow([k, t["launches"], round(t["avg_ns"], 1), t["min_ns"], t["max_ns"], t["skipped_before"]])
+
 counters = {}
-for leg in ("fetch", "write", "sq"):
-    f = one(f"prof_{tag}_{leg}/*/*_counter_collection.csv")
-    if not f:
-        continue
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    meta = {}
-    for r in csv.DictReader(open(f)):
-        if "frad::" not in r["Kernel_Name"]:
-            continue
-        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        meta[r["Kernel_Name"]] = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size", "Grid_Size", "Workgroup_Size")}
-    for k, d in agg.items():
-        e = counters.setdefault(k, {"launch": meta[k]})
-        for c, v in d.items():
-            e[c] = sum(v) / len(v)
-for k, e in counters.items():
-    if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
-        # units: KiB per dispatch; FETCH_SIZE under-counts wide coalesced reads by exactly 2x on gfx950
-        e["hbm_bytes_per_launch_corrected"] = int((2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024)
-        e["hbm_bytes_per_launch_raw"] = int((e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024)
+for part in ("bench", "other"):
+    f = os.path.join(src, f"pmc_{tag}_{part}.json")
+    if os.path.exists(f):
+        for k, e in json.load(open(f)).items():
+            e["workload"] = "bench.py --steps 3 --warmup 1" if part == "bench" else "tools/pmc_workload.py"
+            counters[k] = e
 # which build these counters belong to: bench.py only quotes `roofline.traffic` from a file whose kernel sources match
 import hashlib
 import subprocess
