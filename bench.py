@@ -334,9 +334,9 @@ def main():
     tsrc = None
     if args.workload == "cfg2":
         try:
-            cnt = json.load(open(os.path.join(ROOT, "profiles", "r02_counters.json")))
+            cnt = json.load(open(os.path.join(ROOT, "profiles", "r03_counters.json")))
             meta = cnt.get("_meta", {})
-            tsrc = {"file": "profiles/r02_counters.json", "csrc_sha": meta.get("csrc_sha"), "git": meta.get("git")}
+            tsrc = {"file": "profiles/r03_counters.json", "csrc_sha": meta.get("csrc_sha"), "git": meta.get("git")}
             if meta.get("csrc_sha") == csrc_fingerprint():
                 for r, key in ((r_enc, "k_p0_fwd"), (r_dec, "k_p0_inv")):
                     hit = [v for k, v in cnt.items() if key in k and isinstance(v, dict) and int(v.get("hbm_bytes_per_launch_corrected", 0)) > 1e8]

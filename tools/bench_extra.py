@@ -64,7 +64,7 @@ pcm4 = (torch.rand((F * N, C), generator=g, device=dev) * 1.8 - 0.9).to(torch.fl
 S = F * N * C
 enc = core.analogue_batch(0, pcm4, "f32le", F, N, C, 32, check_overflow=False)
 o = torch.empty((F, N, C), dtype=torch.float64, device=dev)
-out.append(line("cfg4 p0 encode f32 8ch N=4096 (f32 compute)", S * 8, timeit(lambda: core.analogue_batch(0, pcm4, "f32le", F, N, C, 32, check_overflow=False, out=enc.payload, absmax=enc.absmax)), S))
+out.append(line("cfg4 p0 encode f32 8ch N=4096 (f32 compute, half-frame blocks)", S * 8, timeit(lambda: core.analogue_batch(0, pcm4, "f32le", F, N, C, 32, check_overflow=False, out=enc.payload, absmax=enc.absmax)), S))
 out.append(line("cfg4 p0 decode (f64, channel-group kernel)", S * 12, timeit(lambda: core.digital_batch(0, enc.payload, F, N, C, 32, out=o)), S))
 # cfg 3: one GPU's share (512) of 4096 x 1 s stereo clips: 23 full frames + an 896-sample tail frame per clip
 clips, n3 = 512, 48000
@@ -80,8 +80,8 @@ out.append(line("cfg3 full frames decode", S3 * 12, timeit(lambda: core.digital_
 et3 = core.analogue_batch(0, tails3, "s16le", clips, tail3, 2, 32, check_overflow=False)
 ot3 = torch.empty((clips, tail3, 2), dtype=torch.float64, device=dev)
 St = clips * tail3 * 2
-out.append(line("cfg3 tail frames encode (512 x N=896, Bluestein)", St * 6, timeit(lambda: core.analogue_batch(0, tails3, "s16le", clips, tail3, 2, 32, check_overflow=False, out=et3.payload, absmax=et3.absmax)), St))
-out.append(line("cfg3 tail frames decode (512 x N=896, Bluestein)", St * 12, timeit(lambda: core.digital_batch(0, et3.payload, clips, tail3, 2, 32, out=ot3)), St))
+out.append(line("cfg3 tail frames encode (512 x N=896 = 7 x 128, mixed-radix kernels)", St * 6, timeit(lambda: core.analogue_batch(0, tails3, "s16le", clips, tail3, 2, 32, check_overflow=False, out=et3.payload, absmax=et3.absmax)), St))
+out.append(line("cfg3 tail frames decode (512 x N=896 = 7 x 128, mixed-radix kernels)", St * 12, timeit(lambda: core.digital_batch(0, et3.payload, clips, tail3, 2, 32, out=ot3)), St))
 # cfg 5: 60 s stereo s16, profile 1, N = 2048, hop 1920, loss level 20
 N, C, hop = 2048, 2, 1920
 n = 60 * 48000
