@@ -31,6 +31,14 @@ int g_wave_hip = 0;
 
 template <int LG, int CC, int BITS>
 void go_fwd_wave(const void* blob, int grid, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* am, const Geom& g) {
+    if constexpr (LG == 1) {                                  // clip batches (frad_p0_analogue_clips): 16-bit PCM has the variant
+        if (g.fpc > 0) {
+            allow_lds(k_p0_fwd_wave<LG, CC, BITS, true>, kWaveLdsBytes);
+            hipLaunchKernelGGL((k_p0_fwd_wave<LG, CC, BITS, true>), dim3(grid), dim3(64 * kWaveWaves), kWaveLdsBytes, s, pcm, pay, am,
+                               static_cast<const cx<double>*>(blob), g);
+            return;
+        }
+    }
     allow_lds(k_p0_fwd_wave<LG, CC, BITS>, kWaveLdsBytes);
     hipLaunchKernelGGL((k_p0_fwd_wave<LG, CC, BITS>), dim3(grid), dim3(64 * kWaveWaves), kWaveLdsBytes, s, pcm, pay, am,
                        static_cast<const cx<double>*>(blob), g);
@@ -59,6 +67,12 @@ void go_fwd_wave_lg(int lg, const void* blob, int grid, hipStream_t s, const uns
 
 template <int CC, int BITS>
 void go_inv_wave(const void* blob, int grid, hipStream_t s, const unsigned char* pay, double* out, const Geom& g) {
+    if (g.fpc > 0) {                                          // clip batches (frad_p0_digital_clips)
+        allow_lds(k_p0_inv_wave<CC, BITS, true>, kWaveLdsBytes);
+        hipLaunchKernelGGL((k_p0_inv_wave<CC, BITS, true>), dim3(grid), dim3(64 * kWaveWaves), kWaveLdsBytes, s, pay, out,
+                           static_cast<const cx<double>*>(blob), g);
+        return;
+    }
     allow_lds(k_p0_inv_wave<CC, BITS>, kWaveLdsBytes);
     hipLaunchKernelGGL((k_p0_inv_wave<CC, BITS>), dim3(grid), dim3(64 * kWaveWaves), kWaveLdsBytes, s, pay, out,
                        static_cast<const cx<double>*>(blob), g);
@@ -132,6 +146,7 @@ bool wave_geometry(int N, int C, int bits) { return N == 2048 && (C == 1 || C ==
 int launch_p0_fwd_wave(int lg, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* am, const Geom& g, int ai, int ao,
                        void (*unit)(long long, long long, long double&, long double&)) {
     if (wave_disabled() || !wave_geometry(g.N, g.C, g.bits) || !ai || !ao || g.n_valid != g.N) return 0;
+    if (g.fpc > 0 && lg != 1) return 0;                       // clip batches: the 16-bit PCM variant only (others: strided copy + flat batch)
     if ((g.dtype >> 3) == 2 && ((g.dtype >> 1) & 3) <= 2) return 0;   // f16 / f32 PCM: float32 compute stays with the f32 kernels
     const void* blob = wave_blob(unit);
     if (blob == nullptr) return 0;

@@ -768,7 +768,9 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
 #define FRAD_WAVE_PRB 4
 #endif
 
-template <int LG, int CC, int BITS, int MODE, typename P1>
+// CLIPS: the batch is a set of equally cut clips (Geom::fpc, clip_stride; frad_p0_analogue_clips) -- a variant of its own, so
+// that the flat batch keeps its frame stride in one scalar product (the clip arithmetic cost the headline kernel its registers)
+template <int LG, int CC, int BITS, int MODE, typename P1, bool CLIPS = false>
 __device__ __forceinline__ void
 wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload, double* absmax,
               const cx<double>* __restrict__ blob, const Geom& g, const P1& pw) {
@@ -805,6 +807,10 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // provably wave-uniform: unit numbers and frame bases stay in SGPRs
 #endif
     unsigned char* wbuf = smem + kWaveTableBytes + wv * kWaveBufBytes;
+    const long long frameb = (g.frame_stride * CC) << LG;
+    auto frame_off = [&](long long f) -> long long {          // byte offset of frame f in the PCM buffer
+        if constexpr (CLIPS) return (frame_base(g, f) * CC) << LG; else return f * frameb;
+    };
     const long long n_units = (g.n_frames + FPW - 1) / FPW;
     // units [ub, ue) belong to this block; its waves draw them from an LDS counter (the first kWaveWaves statically)
     const long long ub = n_units * blockIdx.x / gridDim.x, ue = n_units * (blockIdx.x + 1) / gridDim.x;
@@ -824,7 +830,7 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
     auto dma_in = [&](long long u) {
         if constexpr (STAGED) {
             const int h = lane >> 5, l = lane & 31;
-            const unsigned char* src = pcm + ((frame_base(g, frame_of(u, h)) * CC) << LG) + (CC == 2 ? lane : l) * 16;
+            const unsigned char* src = pcm + frame_off(frame_of(u, h)) + (CC == 2 ? lane : l) * 16;
 #pragma unroll
             for (int i = 0; i < NDMA; ++i) {
 #ifdef FRAD_HOST_EMULATION
@@ -931,7 +937,7 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
             team_sync<64>();                                   // raw bytes consumed: the buffer may be overwritten
         } else {
             // ---- wide elements: one global load per element, no staging ---------------------------
-            const unsigned char* fb = pcm + ((frame_base(g, frame_of(u, h)) * CC) << LG) + (CC == 2 ? (h << LG) : 0);
+            const unsigned char* fb = pcm + frame_off(frame_of(u, h)) + (CC == 2 ? (h << LG) : 0);
             dispatch_pcm<LG>(g.dtype, g.raw_be, [&](auto code_tag, auto raw_tag) {
                 constexpr int CODE = decltype(code_tag)::value;
                 constexpr bool RAW = decltype(raw_tag)::value != 0;
@@ -1201,11 +1207,11 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
     FRAD_STAMP_FLUSH;
 }
 
-template <int LG, int CC, int BITS>
+template <int LG, int CC, int BITS, bool CLIPS = false>
 __global__ void FRAD_WAVE_BOUNDS
 k_p0_fwd_wave(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload, double* absmax,
               const cx<double>* __restrict__ blob, Geom g) {
-    wave_fwd_body<LG, CC, BITS, 0>(pcm, payload, absmax, blob, g, P1None{});
+    wave_fwd_body<LG, CC, BITS, 0, P1None, CLIPS>(pcm, payload, absmax, blob, g, P1None{});
 }
 // K7: PCM -> q int32 [n_frames, 2048, C] + pw.tq_out [n_frames, 27, C]  (full frames, integer or f64 PCM)
 template <int LG, int CC>
@@ -1248,7 +1254,7 @@ template <typename T> __device__ __forceinline__ cx<T> cmulc(cx<T> a, cx<T> w) {
 // OUT: -1 = float64 samples out (the reference's `digital`); a FRAD_PCM_* code = the decoder's from_f64 conversion fused
 // into the output stage (CC == 2): the staged float64 rows come back four sample-frames per lane, are converted and
 // leave as 8 x itemsize contiguous bytes per lane -- 4-6 B per sample over HBM instead of 8.
-template <int CC, int BITS, int MODE, typename P1, int OUT = -1>
+template <int CC, int BITS, int MODE, typename P1, int OUT = -1, bool CLIPS = false>
 __device__ __forceinline__ void
 wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ out, const cx<double>* __restrict__ blob, const Geom& g, const P1& pw) {
     using T = double;
@@ -1559,7 +1565,8 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
             const bool live = f < g.n_frames;
             int lq = l, hq = h;
             FRAD_OPAQUE(lq); FRAD_OPAQUE(hq);
-            const long long fbase = frame_base(g, live ? f : 0);      // first sample-frame of the output frame (frame_stride = N)
+            long long fbase;                                      // first sample-frame of the output frame
+            if constexpr (CLIPS) fbase = frame_base(g, live ? f : 0); else fbase = (live ? f : 0) * (long long)N;
             unsigned char* dstf = reinterpret_cast<unsigned char*>(out + fbase * CC);
             // staging position of local sample-frame S = 4 n + r (n = lane's quad inside the block, r = 0..3), see header:
             //   CC == 2: 16-byte rows R = S, physical row R ^ ((R >> 3) & 7), channel h in the row's half
@@ -1684,10 +1691,10 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
     }
 }
 
-template <int CC, int BITS>
+template <int CC, int BITS, bool CLIPS = false>
 __global__ void FRAD_WAVE_BOUNDS
 k_p0_inv_wave(const unsigned char* __restrict__ payload, double* __restrict__ out, const cx<double>* __restrict__ blob, Geom g) {
-    wave_inv_body<CC, BITS, 0>(payload, out, blob, g, P1None{});
+    wave_inv_body<CC, BITS, 0, P1None, -1, CLIPS>(payload, out, blob, g, P1None{});
 }
 // profile 0 decode straight to a narrower PCM format (stereo frames, or pairs of mono frames): frad_p0_digital_pcm
 template <int BITS, int OUT, int CC = 2>
