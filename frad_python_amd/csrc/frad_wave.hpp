@@ -104,8 +104,9 @@ __device__ unsigned long long g_wave_stamps[16];
 #define FRAD_STAMP_FLUSH ((void)0)
 #endif
 
-// section marks for tools/asm_stats.py (a comment in the assembly, no instruction)
-#ifndef FRAD_HOST_EMULATION
+// section marks for tools/asm_stats.py: a comment in the assembly, no instruction -- but an asm statement the scheduler will not
+// move code across, so diagnostic builds only (hipcc -DFRAD_ASM_MARKS --cuda-device-only -S ...)
+#if defined(FRAD_ASM_MARKS) && !defined(FRAD_HOST_EMULATION)
 #define FRAD_MARK(name) asm volatile("; FRAD_MARK " name)
 #else
 #define FRAD_MARK(name) ((void)0)

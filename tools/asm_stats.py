@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction mix of the kernels in a gfx950 assembly file (hipcc --cuda-device-only -S).
 
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off --cuda-device-only -S frad_p1_wave.hip -o /tmp/p1w.s
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DFRAD_ASM_MARKS --cuda-device-only -S frad_p1_wave.hip -o /tmp/p1w.s
     python tools/asm_stats.py /tmp/p1w.s [name substring]
 
 The wave kernels are fully unrolled inside their unit loop, so the static count of the loop body is the dynamic count
