@@ -53,7 +53,7 @@ __host__ __device__ constexpr double rk_sin(int R, int m) {
 // R-point DFT in registers, e^(-2 pi i j k / R) (forward) or its conjugate: the sums / differences of the mirrored inputs
 // halve the products (y_j e^(-i t) + y_(R-j) e^(+i t) = (y_j + y_(R-j)) cos t - i (y_j - y_(R-j)) sin t)
 template <int R, bool INV>
-__device__ __forceinline__ void dft_small(cx<double> (&y)[7]) {
+__device__ __forceinline__ void dft_small(cx<double> (&y)[R]) {
     constexpr int H = (R - 1) / 2;
     cx<double> sm[H], df[H], out[R];
 #pragma unroll
@@ -107,25 +107,30 @@ __device__ __forceinline__ void sub_ffts(cx<double>* zb, int nsub, int log2p, co
     }
 }
 
-// twiddle + radix-r butterfly over the r sub-buffers of every channel, in place: (buffer b, slot k1) -> (buffer k2, slot k1)
-template <bool INV>
-__device__ __forceinline__ void radix_pass(cx<double>* zb, int C, const MixedTab& mt) {
-    const int r = mt.r, log2p = mt.log2p, P = 1 << log2p, sh = plan_sh(log2p);
+// twiddle + radix-r butterfly over the r sub-buffers of every channel, in place: (buffer b, slot k1) -> (buffer k2, slot k1).
+// (R is a template parameter: a register array indexed under a run-time radix would live in scratch memory.)
+template <int R, bool INV>
+__device__ __forceinline__ void radix_pass_r(cx<double>* zb, int C, const MixedTab& mt) {
+    const int log2p = mt.log2p, P = 1 << log2p, sh = plan_sh(log2p);
     for (int i = threadIdx.x; i < C * P; i += blockDim.x) {
         const int c = i >> log2p, k1 = i & (P - 1);
-        cx<double>* base = zb + ((long long)(c * r) << log2p) + pslot_p(k1, sh);
-        cx<double> y[7];
+        cx<double>* base = zb + ((long long)(c * R) << log2p) + pslot_p(k1, sh);
+        cx<double> y[R];
 #pragma unroll
-        for (int b = 0; b < 7; ++b) if (b < r) y[b] = base[(long long)b << log2p];
+        for (int b = 0; b < R; ++b) y[b] = base[(long long)b << log2p];
 #pragma unroll
-        for (int b = 1; b < 7; ++b) if (b < r) {
+        for (int b = 1; b < R; ++b) {
             const cx<double> w = mt.tw2[(b - 1) * P + k1];
             y[b] = cmul(y[b], INV ? conj(w) : w);
         }
-        if (r == 3) dft_small<3, INV>(y); else if (r == 5) dft_small<5, INV>(y); else dft_small<7, INV>(y);
+        dft_small<R, INV>(y);
 #pragma unroll
-        for (int b = 0; b < 7; ++b) if (b < r) base[(long long)b << log2p] = y[b];
+        for (int b = 0; b < R; ++b) base[(long long)b << log2p] = y[b];
     }
+}
+template <bool INV>
+__device__ __forceinline__ void radix_pass(cx<double>* zb, int C, const MixedTab& mt) {
+    if (mt.r == 3) radix_pass_r<3, INV>(zb, C, mt); else if (mt.r == 5) radix_pass_r<5, INV>(zb, C, mt); else radix_pass_r<7, INV>(zb, C, mt);
 }
 
 // time plane xa [C][N] (natural order) -> coefficient plane xa [C][N]; zb = complex plane [C][M]
@@ -325,31 +330,30 @@ __global__ void __launch_bounds__(Plan<L2>::TEAM) k_gm_sub(cx<double>* __restric
 }
 
 // forward: columns k1 and P - k1 of a row -> twiddle + radix-r -> the r pairs (k, M - k) they hold -> pair step -> X
+template <int R>
 __global__ void __launch_bounds__(256) k_gm_radix_post(const cx<double>* __restrict__ zw, double* __restrict__ out, MixedTab mt, int N, int C,
                                                        long long fstride, long long cstride, long long ostride) {
-    const int r = mt.r, log2p = mt.log2p, P = 1 << log2p, M = N / 2, H = M / 2;
+    const int log2p = mt.log2p, P = 1 << log2p, M = N / 2, H = M / 2;
     const long long row = blockIdx.y;
     const cx<double>* z = zw + row * (long long)M;
     double* o = out + (row / C) * fstride + (row % C) * cstride;
     const double sc = 1.0 / (double)(2 * N), sc2 = K<double>::s2 / (double)(2 * N);
     for (int k1 = blockIdx.x * blockDim.x + threadIdx.x; k1 <= P / 2; k1 += gridDim.x * blockDim.x) {
         const int k1m = (P - k1) & (P - 1);
-        cx<double> ya[7], yb[7];
+        cx<double> ya[R], yb[R];
 #pragma unroll
-        for (int b = 0; b < 7; ++b) if (b < r) {
+        for (int b = 0; b < R; ++b) {
             ya[b] = z[((long long)b << log2p) + k1]; yb[b] = z[((long long)b << log2p) + k1m];
             if (b > 0) { ya[b] = cmul(ya[b], mt.tw2[(b - 1) * P + k1]); yb[b] = cmul(yb[b], mt.tw2[(b - 1) * P + k1m]); }
         }
-        if (r == 3) { dft_small<3, false>(ya); dft_small<3, false>(yb); }
-        else if (r == 5) { dft_small<5, false>(ya); dft_small<5, false>(yb); }
-        else { dft_small<7, false>(ya); dft_small<7, false>(yb); }
+        dft_small<R, false>(ya); dft_small<R, false>(yb);
         // ya[k2] = Z[k1 + P k2], yb[k2] = Z[k1m + P k2]; partner of k = k1 + P k2 is M - k = k1m + P (r - 1 - k2) (k1 > 0) or P (r - k2) (k1 = 0)
 #pragma unroll
-        for (int k2 = 0; k2 < 7; ++k2) if (k2 < r) {
+        for (int k2 = 0; k2 < R; ++k2) {
             const int k = k1 + (k2 << log2p);
             if (k > H) continue;                              // each pair once: k in [0, M/2]
             cx<double> zm;
-            if (k1 == 0) zm = k2 == 0 ? ya[0] : ya[r - k2]; else zm = yb[r - 1 - k2];
+            if (k1 == 0) zm = k2 == 0 ? ya[0] : ya[(R - k2) % R]; else zm = yb[R - 1 - k2];
             const cx<double> zk = ya[k2], zp = conj(zm);
             const cx<double> p = cmul(zk + zp, mt.post[2 * k]), q = cmul(zk - zp, mt.post[2 * k + 1]);
             const cx<double> S = p + q, D = p - q;
@@ -363,10 +367,10 @@ __global__ void __launch_bounds__(256) k_gm_radix_post(const cx<double>* __restr
         // the pairs whose smaller member sits in column k1m (k = k1m + P k2 <= M/2), unless the two columns coincide
         if (k1m != k1) {
 #pragma unroll
-            for (int k2 = 0; k2 < 7; ++k2) if (k2 < r) {
+            for (int k2 = 0; k2 < R; ++k2) {
                 const int k = k1m + (k2 << log2p);
                 if (k > H) continue;
-                const cx<double> zk = yb[k2], zp = conj(ya[r - 1 - k2]);
+                const cx<double> zk = yb[k2], zp = conj(ya[R - 1 - k2]);
                 const cx<double> p = cmul(zk + zp, mt.post[2 * k]), q = cmul(zk - zp, mt.post[2 * k + 1]);
                 const cx<double> S = p + q, D = p - q;
                 o[(long long)k * ostride] = S.x * sc;
@@ -398,22 +402,23 @@ __global__ void __launch_bounds__(256) k_gm_pre_inverse(const double* __restrict
 }
 
 // inverse, step 3: conjugate twiddle + radix-r -> z[m1 + P m2] -> Makhoul's permutation undone -> out (strided)
+template <int R>
 __global__ void __launch_bounds__(256) k_gm_radix_unpack(const cx<double>* __restrict__ zw, double* __restrict__ out, MixedTab mt, int N, int C,
                                                          long long fstride, long long cstride, long long ostride) {
-    const int r = mt.r, log2p = mt.log2p, P = 1 << log2p, M = N / 2, H = M / 2;
+    const int log2p = mt.log2p, P = 1 << log2p, M = N / 2, H = M / 2;
     const long long row = blockIdx.y;
     const cx<double>* z = zw + row * (long long)M;
     double* o = out + (row / C) * fstride + (row % C) * cstride;
     for (int k1 = blockIdx.x * blockDim.x + threadIdx.x; k1 < P; k1 += gridDim.x * blockDim.x) {
-        cx<double> y[7];
+        cx<double> y[R];
 #pragma unroll
-        for (int b = 0; b < 7; ++b) if (b < r) {
+        for (int b = 0; b < R; ++b) {
             y[b] = z[((long long)b << log2p) + k1];
             if (b > 0) y[b] = cmul(y[b], conj(mt.tw2[(b - 1) * P + k1]));
         }
-        if (r == 3) dft_small<3, true>(y); else if (r == 5) dft_small<5, true>(y); else dft_small<7, true>(y);
+        dft_small<R, true>(y);
 #pragma unroll
-        for (int m2 = 0; m2 < 7; ++m2) if (m2 < r) {
+        for (int m2 = 0; m2 < R; ++m2) {
             const int m = k1 + (m2 << log2p);
             if (m < H) { o[(long long)(4 * m) * ostride] = y[m2].x; o[(long long)(4 * m + 2) * ostride] = y[m2].y; }
             else { const int q = M - 1 - m; o[(long long)(4 * q + 3) * ostride] = y[m2].x; o[(long long)(4 * q + 1) * ostride] = y[m2].y; }
@@ -592,11 +597,15 @@ int global_dct_mixed(bool fwd, const double* in, double* out, void* zw, int N, i
     if (fwd) {
         hipLaunchKernelGGL(k_gm_pack, dim3(bx(M / 2), (unsigned)rows), dim3(256), 0, s, in, z, N, mt.r, mt.log2p);
         sub_any(std::false_type{});
-        hipLaunchKernelGGL(k_gm_radix_post, dim3(bx(P / 2 + 1), (unsigned)rows), dim3(256), 0, s, z, out, mt, N, C, fstride, cstride, ostride);
+#define GO(RR) hipLaunchKernelGGL(k_gm_radix_post<RR>, dim3(bx(P / 2 + 1), (unsigned)rows), dim3(256), 0, s, z, out, mt, N, C, fstride, cstride, ostride)
+        if (mt.r == 3) GO(3); else if (mt.r == 5) GO(5); else GO(7);
+#undef GO
     } else {
         hipLaunchKernelGGL(k_gm_pre_inverse, dim3(bx(M / 2 + 1), (unsigned)rows), dim3(256), 0, s, in, z, mt, N);
         sub_any(std::true_type{});
-        hipLaunchKernelGGL(k_gm_radix_unpack, dim3(bx(P), (unsigned)rows), dim3(256), 0, s, z, out, mt, N, C, fstride, cstride, ostride);
+#define GO(RR) hipLaunchKernelGGL(k_gm_radix_unpack<RR>, dim3(bx(P), (unsigned)rows), dim3(256), 0, s, z, out, mt, N, C, fstride, cstride, ostride)
+        if (mt.r == 3) GO(3); else if (mt.r == 5) GO(5); else GO(7);
+#undef GO
     }
     if (hipGetLastError() != hipSuccess) return FRAD_E_HIP;
     return 1;

@@ -66,6 +66,7 @@ def kernels(path: str = LIB):
     names = [r["name"] for r in rows]
     dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
     for r, d in zip(rows, dem):
+        d = d.replace("(anonymous namespace)::", "")
         r["demangled"] = re.sub(r"\(.*$", "", d).replace("void frad::", "").replace("frad::", "")
     return rows
 
