@@ -12,7 +12,8 @@ def main(root, tag):
     for leg in "abfw":
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         meta = {}
-        for f in glob.glob(os.path.join(root, "gpurun_out", f"pmc_{tag}_{leg}", "*", "*_counter_collection.csv")):
+        files = glob.glob(os.path.join(root, "gpurun_out", f"pmc_{tag}_{leg}", "*", "*_counter_collection.csv"))
+        for f in sorted(files, key=os.path.getmtime)[-1:]:      # gpurun_out/ accumulates runs: the newest one only
             for r in csv.DictReader(open(f)):
                 if "frad::" in r["Kernel_Name"]:
                     k = short(r["Kernel_Name"])
