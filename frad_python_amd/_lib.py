@@ -85,6 +85,13 @@ class FradLib:
                 "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
                 "There is no CPU fallback for the product path.")
         self.path = path
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and must be the one that gets loaded.  If this
+        # library came first it would bind /opt/rocm's copy, torch would then bring a second runtime, and every launch here
+        # would fail with hipErrorNoDevice (seen when build() and smoke() run in one process).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         self.dll = ctypes.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(self.dll, name)           # AttributeError if the library lacks a symbol
