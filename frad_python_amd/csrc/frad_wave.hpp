@@ -809,8 +809,9 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
 #endif
     unsigned char* wbuf = smem + kWaveTableBytes + wv * kWaveBufBytes;
     const long long frameb = (g.frame_stride * CC) << LG;
+    [[maybe_unused]] const long long gapb = ((g.clip_stride - (long long)g.fpc * g.frame_stride) * CC) << LG;   // bytes skipped between clips
     auto frame_off = [&](long long f) -> long long {          // byte offset of frame f in the PCM buffer
-        if constexpr (CLIPS) return (frame_base(g, f) * CC) << LG; else return f * frameb;
+        if constexpr (CLIPS) return f * frameb + (long long)((unsigned)f / (unsigned)g.fpc) * gapb; else return f * frameb;
     };
     const long long n_units = (g.n_frames + FPW - 1) / FPW;
     // units [ub, ue) belong to this block; its waves draw them from an LDS counter (the first kWaveWaves statically)
@@ -1567,7 +1568,8 @@ wave_inv_body(const unsigned char* __restrict__ payload, double* __restrict__ ou
             int lq = l, hq = h;
             FRAD_OPAQUE(lq); FRAD_OPAQUE(hq);
             long long fbase;                                      // first sample-frame of the output frame
-            if constexpr (CLIPS) fbase = frame_base(g, live ? f : 0); else fbase = (live ? f : 0) * (long long)N;
+            if constexpr (CLIPS) { const long long ff = live ? f : 0; fbase = ff * (long long)N + (long long)((unsigned)ff / (unsigned)g.fpc) * (g.clip_stride - (long long)g.fpc * N); }
+            else fbase = (live ? f : 0) * (long long)N;
             unsigned char* dstf = reinterpret_cast<unsigned char*>(out + fbase * CC);
             // staging position of local sample-frame S = 4 n + r (n = lane's quad inside the block, r = 0..3), see header:
             //   CC == 2: 16-byte rows R = S, physical row R ^ ((R >> 3) & 7), channel h in the row's half
