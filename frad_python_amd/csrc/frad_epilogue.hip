@@ -212,6 +212,11 @@ int frad_p0_digital_pcm(const void* payload, int64_t payload_stride, int64_t n_f
             return FRAD_OK;
         }
     }
+    {   // every other LDS-resident kernel converts in its own store (one pass, no scratch); only the unit / two-pass whole-row kernels'
+        // geometries are rerouted to their one-shot twins for it, and frames wider than a CU keep the second pass
+        const int r = p0_digital_out(payload, payload_stride, n_frames, N, C, bits, flags, out_dtype, pcm_out, stream);
+        if (r != 1) return r;
+    }
     Scratch ws(s);
     const size_t n = (size_t)n_frames * N * C;
     if (hipMallocAsync(&ws.p, n * 8, s) != hipSuccess) return FRAD_E_NOMEM;
@@ -227,6 +232,10 @@ int frad_p1_digital_pcm(const int32_t* q, const int32_t* tq, int64_t n_frames, i
     if (n_frames < 0 || N < 1 || C < 1) return FRAD_E_INVALID;
     if (n_frames == 0) return FRAD_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    {
+        const int r = p1_digital_out(q, tq, n_frames, N, C, bits, srate, out_dtype, flags, pcm_out, stream);   // one pass where the kernel's store converts
+        if (r != 1) return r;
+    }
     Scratch ws(s);
     const size_t n = (size_t)n_frames * N * C;
     if (hipMallocAsync(&ws.p, n * 8, s) != hipSuccess) return FRAD_E_NOMEM;

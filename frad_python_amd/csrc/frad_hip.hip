@@ -501,8 +501,16 @@ int p0_analogue_impl(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
 }
 
 int p0_digital_impl(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C, int32_t bits,
-                    uint32_t flags, double* pcm_out, void* stream, int fpc, long long clip_stride);
+                    uint32_t flags, double* pcm_out, void* stream, int fpc, long long clip_stride, int out_dtype = FRAD_PCM_F64LE);
 }  // namespace
+namespace frad {
+// frad_p0_digital with the decoder's output conversion applied by the kernel's own store (frad_epilogue.hip: frad_p0_digital_pcm).
+// FRAD_OK = done; 1 = this geometry's kernel cannot convert (the caller decodes to float64 scratch and converts in a second pass)
+int p0_digital_out(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C, int32_t bits, uint32_t flags,
+                   int out_dtype, void* pcm_out, void* stream) {
+    return p0_digital_impl(payload, payload_stride, n_frames, N, C, bits, flags, static_cast<double*>(pcm_out), stream, 0, 0, out_dtype);
+}
+}  // namespace frad
 extern "C" {
 
 int frad_p0_digital(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C, int32_t bits,
@@ -521,7 +529,9 @@ int frad_p0_digital_clips(const void* payload, int64_t payload_stride, int64_t n
 namespace {
 
 int p0_digital_impl(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C, int32_t bits,
-                    uint32_t flags, double* pcm_out, void* stream, int fpc, long long clip_stride) {
+                    uint32_t flags, double* pcm_out, void* stream, int fpc, long long clip_stride, int out_dtype) {
+    const bool conv = out_dtype != FRAD_PCM_F64LE;            // the store converts (one-shot / channel-group / mixed-radix / Bluestein / direct kernels)
+    if (conv && fpc > 0) return 1;
     int rc = check_common(payload, pcm_out, n_frames, N, C, bits);
     if (rc != FRAD_OK) return rc;
     if (n_frames == 0) return FRAD_OK;
@@ -529,10 +539,11 @@ int p0_digital_impl(const void* payload, int64_t payload_stride, int64_t n_frame
     hipStream_t s = static_cast<hipStream_t>(stream);
     Geom g = make_geom(n_frames, N, C, N, payload_stride, bits, flags, FRAD_PCM_F64LE);
     g.fpc = fpc; g.clip_stride = clip_stride;
+    if (conv) { g.dtype = out_dtype; g.raw_be = (flags & FRAD_RAW_BE_INTS) ? 1 : 0; }
     const int ai = (aligned16(payload) && payload_stride % 16 == 0) ? 1 : 0;
     const unsigned char* in = static_cast<const unsigned char*>(payload);
     const int aout = (aligned16(pcm_out) && (fpc == 0 || ((clip_stride * C) * 8) % 16 == 0)) ? 1 : 0;
-    if (launch_p0_inv_wave(s, in, pcm_out, g, ai, aout, unit_neg)) { HIPCHK(hipGetLastError()); return FRAD_OK; }
+    if (!conv && launch_p0_inv_wave(s, in, pcm_out, g, ai, aout, unit_neg)) { HIPCHK(hipGetLastError()); return FRAD_OK; }
     const FastCfg c = fast_cfg(N, C, false);
     if (fpc > 0 && c.ok) {
         // clips through a kernel without clip addressing: the flat batch decodes into a dense scratch, one strided copy scatters it
@@ -550,9 +561,15 @@ int p0_digital_impl(const void* payload, int64_t payload_stride, int64_t n_frame
         // (12-bit pairs may straddle channel groups here: unpacking only reads them; the packing side refuses that)
         g.fpb = c.fpb; g.cg = c.cg;
         if (c.cg == C && ai && C <= 2 && ((long long)N * C) % 32 == 0) g.cc_fast = C;
-        if (c.cg == C && C <= 2 && aligned16(pcm_out)) g.in_mode = C;      // decode: quad store for C = 1 / 2
+        if (!conv && c.cg == C && C <= 2 && aligned16(pcm_out)) g.in_mode = C;      // decode: quad store for C = 1 / 2
         dim3 grid((unsigned)((n_frames + c.fpb - 1) / c.fpb));
-        if (c.cg < C && launch_p0_inv_grp2(c, s, in, pcm_out, tb, g)) {
+        if (conv) {                                          // the kernels whose store converts: one-shot / channel-group
+            // only where frad_p0_digital runs them too (the result must equal from_f64 of ITS samples bit for bit): not the
+            // wave / unit kernels' geometries (N = 1024 / 2048 with 1-2 channels), not the two-pass whole-row kernels'
+            if (((c.log2m == 9 || c.log2m == 10) && C <= 2) || (c.cg < C && C == 2 * c.cg)) return 1;
+            rc = launch_p0_inv(c, grid, s, in, pcm_out, tb, g, ai);
+            if (rc != FRAD_OK) return rc;
+        } else if (c.cg < C && launch_p0_inv_grp2(c, s, in, pcm_out, tb, g)) {
             // whole-row two-pass kernel took it
         } else if (!launch_p0_inv_pers(c, s, in, pcm_out, tb, g)) {
             rc = launch_p0_inv(c, grid, s, in, pcm_out, tb, g, ai);
@@ -578,6 +595,7 @@ int p0_digital_impl(const void* payload, int64_t payload_stride, int64_t n_frame
         }
         const size_t per_frame = 2 * (size_t)N * C * 8;
         if (per_frame > (size_t)kLdsBytes) {
+            if (conv) return 1;                              // (workspace path: float64 rows)
             const int r = global_p0_digital(in, pcm_out, g, flags, s);
             if (r == FRAD_E_HIP) g_last_hip = global_last_hip_error();
             return r;

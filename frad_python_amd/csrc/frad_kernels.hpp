@@ -10,6 +10,7 @@
 //                      table, same load / pack stages.
 // Reference line numbers are in include/frad_hip.h and DESIGN.md.
 #pragma once
+#include <type_traits>
 #include "frad_common.hpp"
 #include "frad_fft.hpp"
 
@@ -818,12 +819,47 @@ __device__ FRAD_NOINLINE void unpack_in_any(const unsigned char* __restrict__ pa
 }
 
 // Epilogue (decode): time samples in LDS -> interleaved float64 [N, C] rows, 16 bytes per lane.
+// Decode with the caller's output conversion applied in the store (frad_p0_digital_pcm / frad_p1_digital_pcm, backend/pcmformat.py:
+// 49-62 + src/decoder.py:23): Geom::dtype names the PCM format the decoded samples leave in (FRAD_PCM_F64LE = 22: plain float64).
+// `fn(KIND, LGS)` runs with the format's kind and log2 size as compile-time tags.
+template <typename F> __device__ __forceinline__ void dispatch_out_format(int dtype, F&& fn) {
+    const int kind = dtype >> 3, lg = (dtype >> 1) & 3;
+#define FRAD_OF(K, L) fn(std::integral_constant<int, K>{}, std::integral_constant<int, L>{})
+    switch (kind * 4 + lg) {
+        case 0: FRAD_OF(0, 0); break; case 1: FRAD_OF(0, 1); break; case 2: FRAD_OF(0, 2); break; case 3: FRAD_OF(0, 3); break;
+        case 4: FRAD_OF(1, 0); break; case 5: FRAD_OF(1, 1); break; case 6: FRAD_OF(1, 2); break; case 7: FRAD_OF(1, 3); break;
+        case 9: FRAD_OF(2, 1); break; case 10: FRAD_OF(2, 2); break; default: FRAD_OF(2, 3); break;
+    }
+#undef FRAD_OF
+}
+template <int LGS> __device__ __forceinline__ void store_pcm_elem(unsigned char* p, u64 b, bool be) {
+    if constexpr (LGS == 0) *FRAD_GPTR(unsigned char, p) = (unsigned char)b;
+    else if constexpr (LGS == 1) *FRAD_GPTR(unsigned short, p) = (unsigned short)(be ? bswap16((uint32_t)b) : (uint32_t)b);
+    else if constexpr (LGS == 2) *FRAD_GPTR(uint32_t, p) = be ? bswap32((uint32_t)b) : (uint32_t)b;
+    else *FRAD_GPTR(u64, p) = be ? bswap64(b) : b;
+}
+
 template <int SH, bool PERMUTE>
 __device__ FRAD_NOINLINE void store_pcm_f64(int smem_off, double* __restrict__ out, const Geom& g,
                                               long long f0, int nfl, int slots) {
     FRAD_DYN_SMEM(smem_base_);
     unsigned char* smem = smem_base_ + smem_off;
     const int N = g.N, C = g.C, NC = N * C;
+    if (g.dtype != 22) {                            // a narrower PCM format: convert on the way out, element by element
+        dispatch_out_format(g.dtype, [&](auto kind_tag, auto lg_tag) {
+            constexpr int KIND = decltype(kind_tag)::value, LGS = decltype(lg_tag)::value;
+            const bool be = (g.dtype & 1) != 0, raw = g.raw_be != 0 && be;
+            for (int fl = 0; fl < nfl; ++fl) {
+                unsigned char* dst = reinterpret_cast<unsigned char*>(out) + ((frame_base(g, f0 + fl) * C) << LGS);
+                for (int e = threadIdx.x; e < NC; e += blockDim.x) {
+                    const int n = e / C, c = e - n * C;
+                    const double v = xslot<double, SH>(smem, fl * C + c, slots, PERMUTE ? makhoul(n, N) : n);
+                    store_pcm_elem<LGS>(dst + ((long long)e << LGS), from_f64_bits<KIND, LGS>(v, raw), be);
+                }
+            }
+        });
+        return;
+    }
     const int pairs = NC / 2;                       // out + f*NC is 16-byte aligned when NC is even
     for (int fl = 0; fl < nfl; ++fl) {
         double* dst = out + frame_base(g, f0 + fl) * C;       // (decode: frame_stride = N)
@@ -1020,6 +1056,19 @@ __device__ FRAD_NOINLINE void store_pcm_group(int smem_off, double* __restrict__
     FRAD_DYN_SMEM(smem_base_);
     unsigned char* smem = smem_base_ + smem_off;
     const int N = g.N, C = g.C;
+    if (g.dtype != 22) {                            // (see store_pcm_f64)
+        dispatch_out_format(g.dtype, [&](auto kind_tag, auto lg_tag) {
+            constexpr int KIND = decltype(kind_tag)::value, LGS = decltype(lg_tag)::value;
+            const bool be = (g.dtype & 1) != 0, raw = g.raw_be != 0 && be;
+            unsigned char* dst = reinterpret_cast<unsigned char*>(out) + ((f * (long long)N * C) << LGS);
+            for (int q = threadIdx.x; q < N * cgn; q += blockDim.x) {
+                const int n = q / cgn, j = q - n * cgn;
+                const double v = xslot<double, SH>(smem, j, slots, makhoul(n, N));
+                store_pcm_elem<LGS>(dst + (((long long)n * C + c0 + j) << LGS), from_f64_bits<KIND, LGS>(v, raw), be);
+            }
+        });
+        return;
+    }
     double* dst = out + f * (long long)N * C;
     if ((cgn & 1) == 0 && (C & 1) == 0 && (c0 & 1) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
         const int half = cgn / 2;                             // two channels = one 16-byte store

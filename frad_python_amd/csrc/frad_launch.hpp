@@ -83,6 +83,10 @@ int mixed_prepare(int N, unit_root_fn unit);
 // the DCT of planar float64 rows in HBM through a complex workspace of rows * N / 2 slots (frames wider than a CU): 1 / 0 / < 0
 int global_dct_mixed(bool fwd, const double* in, double* out, void* zw, int N, int C, long long rows, long long fstride, long long cstride,
                      long long ostride, hipStream_t s, unit_root_fn unit);
+int p0_digital_out(const void* payload, int64_t payload_stride, int64_t n_frames, int32_t N, int32_t C, int32_t bits, uint32_t flags,
+                   int out_dtype, void* pcm_out, void* stream);     // frad_hip.hip: 0 = decoded and converted in one pass, 1 = not this geometry
+int p1_digital_out(const int32_t* q, const int32_t* tq, int64_t n_frames, int32_t N, int32_t C, int32_t bits, int32_t srate,
+                   int out_dtype, uint32_t flags, void* out, void* stream);      // frad_p1.hip: as p0_digital_out
 void unit_root(long long p, long long q, long double& re, long double& im);     // exp(-i pi p / q), q even (frad_hip.hip)
 void mixed_clear();
 int mixed_last_hip_error();

@@ -14,6 +14,8 @@
 using namespace frad;
 
 namespace frad {
+int p1_digital_out(const int32_t* q, const int32_t* tq, int64_t n_frames, int32_t N, int32_t C, int32_t bits, int32_t srate,
+                   int out_dtype, uint32_t flags, void* out, void* stream);
 int launch_p1_fwd_mixed(int lg, hipStream_t s, const unsigned char* pcm, int32_t* q, int32_t* tq, const Geom& g, const P1Tables& tb,
                         int aligned_in, unit_root_fn unit);
 int launch_p1_inv_mixed(hipStream_t s, const int32_t* q, const int32_t* tq, double* out, const Geom& g, const P1Tables& tb, unit_root_fn unit);
@@ -301,6 +303,17 @@ int frad_p1_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
 
 int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32_t N, int32_t C, int32_t bits, int32_t srate,
                     double* pcm_out, void* stream) {
+    return p1_digital_out(q, tq, n_frames, N, C, bits, srate, FRAD_PCM_F64LE, 0, pcm_out, stream);
+}
+
+}  // extern "C"
+namespace frad {
+// frad_p1_digital, optionally with the decoder's output conversion applied by the kernel's own store (frad_p1_digital_pcm):
+// FRAD_OK = done; 1 = this geometry's kernel cannot convert (N = 2048 wave kernel, frames wider than a CU): second pass
+int p1_digital_out(const int32_t* q, const int32_t* tq, int64_t n_frames, int32_t N, int32_t C, int32_t bits, int32_t srate,
+                   int out_dtype, uint32_t flags, void* out, void* stream) {
+    const bool conv = out_dtype != FRAD_PCM_F64LE;
+    double* pcm_out = static_cast<double*>(out);
     if (n_frames < 0 || C < 1 || C > 64 || !legal_compact_size(N)) return FRAD_E_INVALID;
     if (n_frames == 0) return FRAD_OK;
     if (!q || !tq || !pcm_out) return FRAD_E_INVALID;
@@ -308,8 +321,9 @@ int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32
     int rc = make_tables(N, srate, bits, 1.0, tb);
     if (rc != FRAD_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    Geom g = p1_geom(n_frames, N, C, N, N, FRAD_PCM_F64LE, 0);
+    Geom g = p1_geom(n_frames, N, C, N, N, conv ? out_dtype : FRAD_PCM_F64LE, conv ? flags : 0);
     FastCfg c = fast_cfg(N, C, false);
+    if (conv && N == 2048 && C <= 2) return 1;                  // (the table-driven wave kernel writes float64)
     if (N == 2048 && C <= 2 && n_frames < 0x7fffffffLL && p1_fast_fits(c, N, C)) {
         // N = 2048, one or two channels: the table-driven wave kernel, then the exact kernel over the frames it marked (a band
         // code outside [0, 256) or |q| >= 256: none in a sane stream).  The list is stream-ordered scratch: count + one slot per frame.
@@ -377,6 +391,7 @@ int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32
             if (r == 1) return FRAD_OK;
         }
         if (lds > kLds) {
+            if (conv) return 1;
             rc = global_p1_digital(q, tq, pcm_out, g, tb, s);
             if (rc == FRAD_E_HIP) g_last = global_last_hip_error();
             return rc;
@@ -389,6 +404,9 @@ int frad_p1_digital(const int32_t* q, const int32_t* tq, int64_t n_frames, int32
     P1CHK(hipGetLastError());
     return FRAD_OK;
 }
+
+}  // namespace frad
+extern "C" {
 
 int frad_p1_overlap_add(const double* frames, int64_t n_frames, int32_t N, int32_t C, int32_t overlap_ratio,
                         const double* prev_tail, double* ola_out, double* next_tail, void* stream) {

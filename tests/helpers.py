@@ -109,6 +109,15 @@ class EmuBackend:
         self.lib.p1_digital(qq.ctypes.data, tt.ctypes.data, F, N, C, bits, srate, out.ctypes.data)
         return out[:F]
 
+    def p1_digital_pcm(self, q, tq, N, C, bits, srate, fmt):
+        from frad_python_amd.backend.pcmformat import pcm_dtype_code, ff_format_to_numpy_type
+        F = q.shape[0]
+        dt = ff_format_to_numpy_type(fmt)
+        out = np.zeros(F * N * C * dt.itemsize + 16, np.uint8)
+        qq, tt = np.ascontiguousarray(q, np.int32), np.ascontiguousarray(tq, np.int32)
+        self.lib.p1_digital_pcm(qq.ctypes.data, tt.ctypes.data, F, N, C, bits, srate, pcm_dtype_code(fmt), out.ctypes.data)
+        return np.frombuffer(out[:F * N * C * dt.itemsize].tobytes(), dt).reshape(F, N, C)
+
     def from_f64(self, x, fmt):
         from frad_python_amd.backend.pcmformat import pcm_dtype_code, ff_format_to_numpy_type
         x = np.ascontiguousarray(x, np.float64)
@@ -256,6 +265,18 @@ class GpuBackend:
                                     t.from_numpy(np.ascontiguousarray(tq, np.int32)).to(self.dev), N, C, bits, srate)
         t.cuda.synchronize()
         return out.cpu().numpy()
+
+    def p1_digital_pcm(self, q, tq, N, C, bits, srate, fmt):
+        from frad_python_amd.backend.pcmformat import pcm_dtype_code, ff_format_to_numpy_type, itemsize_of
+        from frad_python_amd import _lib
+        t = self.torch
+        F = q.shape[0]
+        dt = ff_format_to_numpy_type(fmt)
+        qq = t.from_numpy(np.ascontiguousarray(q, np.int32)).to(self.dev); tt = t.from_numpy(np.ascontiguousarray(tq, np.int32)).to(self.dev)
+        out = t.zeros(F * N * C * dt.itemsize + 16, dtype=t.uint8, device=self.dev)
+        _lib.load().p1_digital_pcm(qq.data_ptr(), tt.data_ptr(), F, N, C, bits, srate, pcm_dtype_code(fmt), out.data_ptr(), int(t.cuda.current_stream().cuda_stream))
+        t.cuda.synchronize()
+        return np.frombuffer(out[:F * N * C * dt.itemsize].cpu().numpy().tobytes(), dt).reshape(F, N, C)
 
     def from_f64(self, x, fmt):
         from frad_python_amd import core

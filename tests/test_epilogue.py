@@ -86,6 +86,35 @@ def _scan_all(lib, data, chunked=None):
     return rows, pos, why
 
 
+@pytest.mark.parametrize("geom", [(1024, 2), (4096, 2), (896, 2), (300, 3), (512, 8), (4096, 8), (2560, 1)])
+@pytest.mark.parametrize("fmt", ["s16le", "f32le", "s32be"])
+def test_decode_with_conversion_in_the_kernels_own_store(be, geom, fmt):
+    """frad_p0_digital_pcm / frad_p1_digital_pcm outside the N = 2048 wave kernels: the one-shot, channel-group, mixed-radix,
+    Bluestein and direct kernels convert in their own store (one pass, no scratch) == from_f64(digital(...)).astype(fmt)."""
+    N, C = geom
+    if be.name == "emu" and N * C > 4096:
+        pytest.skip("emulator: covered by the smaller geometries")
+    F = 3
+    dt = fo.pcm_dtype(fmt)
+    raw = synth.to_pcm(synth.harmonic_mix(F * N, C, 48000, seed=N + C), "s16le")
+    for bits, le in ((32, False), (16, True)):
+        frames = [fo.p0_analogue(fo.to_f64(raw[f * N:(f + 1) * N], fo.pcm_dtype("s16le")), bits, 48000, le) for f in range(F)]
+        pay = np.stack([np.frombuffer(fr[0], np.uint8) for fr in frames])
+        got = be.digital_pcm(0, pay, F, N, C, bits, le, fmt)
+        f64 = be.digital(0, pay, F, N, C, bits, le)
+        with np.errstate(all="ignore"):
+            want = fo.from_f64(f64, dt).astype(dt)
+        assert got.tobytes() == want.tobytes(), (N, C, bits, fmt)
+    # profile 1 at the compact sizes among them
+    if N in (1024, 4096, 896, 512, 2560) and C <= 2:
+        q, tq = be.p1_analogue(raw, "s16le", F, N, C, 16, 48000, 0.553)
+        got = be.p1_digital_pcm(q, tq, N, C, 16, 48000, fmt)
+        f64 = be.p1_digital(q, tq, N, C, 16, 48000)
+        with np.errstate(all="ignore"):
+            want = fo.from_f64(f64, dt).astype(dt)
+        assert got.tobytes() == want.tobytes(), ("p1", N, C, fmt)
+
+
 @pytest.mark.parametrize("fmt", ["s16le", "s24le" if False else "s32le", "f32be", "u8", "s16be"])
 def test_overlap_add_with_output_format(be, fmt):
     """frad_p1_overlap_add_pcm == from_f64(frad_p1_overlap_add(...)).astype(fmt) (decoder.py:28-46 then src/decoder.py:23), tail in float64"""
