@@ -47,8 +47,7 @@ k_p0_fwd_half32(const unsigned char* __restrict__ pcm, unsigned char* __restrict
     dct_post<float, LOG2M>(buf, tt, post);
     __syncthreads();
     unsigned char* dst = payload + f * g.payload_stride + part * (OW * 4);
-    u64 mx = 0;
-    bool nan = false;
+    uint32_t mxf = 0;                                         // max |X| as float32 bits: ordered like the values, and a NaN outranks +Inf
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
         const int k = threadIdx.x + i * T;
@@ -58,8 +57,7 @@ k_p0_fwd_half32(const unsigned char* __restrict__ pcm, unsigned char* __restrict
 #pragma unroll
         for (int j = 0; j < CG; ++j) {
             const float v = xslot<float, SH>(smem, j, SLOTS, k);
-            nan |= (v != v);
-            const u64 a = abs_bits((double)v); mx = a > mx ? a : mx;
+            const uint32_t a = f2u(v) & 0x7fffffffu; mxf = a > mxf ? a : mxf;
             const u64 code = storage_code<float>(v, BITS);
             if constexpr (BITS == 16) { uint32_t c = (uint32_t)code & 0xffffu; if (!le) c = bswap16(c); row[j >> 1] |= c << (16 * (j & 1)); }
             else if constexpr (BITS == 32) { row[j] = le ? (uint32_t)code : bswap32((uint32_t)code); }
@@ -68,7 +66,7 @@ k_p0_fwd_half32(const unsigned char* __restrict__ pcm, unsigned char* __restrict
         store_words<OW>(dst + (long long)k * ROW_OUT, row);
     }
     if (absmax != nullptr) {                                  // np.max(np.abs(freqs)): NaN if any coefficient is (profile0.py:24)
-        if (nan) mx = 0x7ff8000000000000ULL;
+        u64 mx = mxf > 0x7f800000u ? 0x7ff8000000000000ULL : d2u((double)u2f(mxf));
         mx = wave_max_u64(mx);
         if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<u64*>(absmax) + f, mx);
     }
