@@ -399,56 +399,57 @@ __device__ __forceinline__ bool decode_stream_2phase(const unsigned char* p, lon
         const int cs = lane * chb, ce = cs + chb;
         // ---- phase 1: the entry map of this lane's chunk ---------------------------------------------------
         if (lane < nch) {
-            // zero run at the chunk's end (it continues into the next chunk); 33 stands for "33 or more"
+            // Everything in chunk-relative positions r = pp - cs.  zcap = first zero run too long for a 32-bit code ("zcap or more").
+            const int zcap = (GW_E - k - 1) / 2 + 1;
+            const int rl1 = last1 - cs, rT = T - cs;                      // last '1' and stream end, relative to this chunk
             int z;
             {
                 const int wn = ce >> 5;                                   // (the last chunks may reach beyond the staged words: zeros)
                 const uint32_t w0 = wn < nwords + 2 ? words[wn] : 0u, w1 = wn + 1 < nwords + 2 ? words[wn + 1] : 0u;
-                z = w0 ? __builtin_clz(w0) : (w1 ? 32 + __builtin_clz(w1) : 33);
-                if (z > 33) z = 33;
+                z = w0 ? __builtin_clz(w0) : (w1 ? 32 + __builtin_clz(w1) : 64);
+                if (z > zcap) z = zcap;
             }
-            // entry of position pp given the zero run z there: either final (`e`, ri < 0) or one more code behind ring slot `ri`.
+            // entry of position r given the zero run z there: either final (`e`, ri < 0) or one more code behind ring slot `ri`.
             // Branch-free (selects): the lanes of a wave sit in different cases at every position.
-            auto classify = [&](int pp, int z_, uint32_t& e, int& ri) {
-                const int clen = 2 * z_ + k + 1, nx = pp + clen;
-                const bool end_ = pp > last1, lng = clen > GW_E, lastc = nx >= T, outc = nx >= ce;
-                uint32_t v = (1u << 7) | ((uint32_t)(nx - ce) & 127u);            // the code ends in the next chunk
+            auto classify = [&](int r, int z_, uint32_t& e, int& ri) {
+                const int rnx = r + 2 * z_ + k + 1;                               // where the next code starts
+                const bool end_ = r > rl1, lng = z_ >= zcap, lastc = rnx >= rT, outc = rnx >= chb;
+                uint32_t v = (uint32_t)(rnx - chb) | (1u << 7);                   // the code ends in the next chunk (exit offset < 32)
                 v = lastc ? ((1u << 7) | GW_END) : v;                             // the stream's last code (maybe cut short)
                 v = lng ? GW_LONG : v;
                 v = end_ ? GW_END : v;                                            // zeros to the end: no code starts here
                 e = v;
-                const int slot = (nx - cs) & (GW_RING - 1);
+                const int slot = rnx & (GW_RING - 1);                             // (cs is a multiple of 32 and the ring index is taken mod 64 of r)
                 ri = (end_ | lng | lastc | outc) ? (slot | (int)0x80000000) : slot;     // sign bit: the ring is not consulted
             };
-            auto finish = [&](uint32_t e, int ri, uint32_t t) -> uint32_t {
-                const uint32_t viaring = (t & 127u) == GW_LONG ? GW_LONG : t + (1u << 7);
-                return ri < 0 ? e : viaring;
-            };
+            // one more code in front of entry t: the count sits above bit 7, so a LONG / END code in the low 7 bits rides along
+            auto finish = [&](uint32_t e, int ri, uint32_t t) -> uint32_t { return ri < 0 ? e : t + (1u << 7); };
             for (int w = (ce >> 5) - 1; w >= (cs >> 5); --w) {
                 const uint32_t cur = w < nwords + 2 ? words[w] : 0u;
+                const int r0 = 32 * w + 31 - cs;                                  // relative position of the word's last bit
                 if (k >= 3) {
 #pragma unroll 2
-                    for (int i = 0; i < 32; i += 4) {                 // positions 32 w + 31 - i ... - 3: mutually independent (k + 1 >= 4)
+                    for (int i = 0; i < 32; i += 4) {                 // positions r0 - i ... - 3: mutually independent (k + 1 >= 4)
                         uint32_t e[4]; int ri[4]; uint32_t t[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const bool one = (cur >> (i + j)) & 1u;
-                            z = one ? 0 : (z < 33 ? z + 1 : 33);
-                            classify(32 * w + 31 - i - j, z, e[j], ri[j]);
+                            z = one ? 0 : (z < zcap ? z + 1 : zcap);
+                            classify(r0 - i - j, z, e[j], ri[j]);
                         }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) t[j] = ring[ri[j] & (GW_RING - 1)];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) ring[(32 * w + 31 - i - j - cs) & (GW_RING - 1)] = (unsigned short)finish(e[j], ri[j], t[j]);
+                        for (int j = 0; j < 4; ++j) ring[(r0 - i - j) & (GW_RING - 1)] = (unsigned short)finish(e[j], ri[j], t[j]);
                     }
                 } else {
                     for (int i = 0; i < 32; ++i) {
                         const bool one = (cur >> i) & 1u;
-                        z = one ? 0 : (z < 33 ? z + 1 : 33);
+                        z = one ? 0 : (z < zcap ? z + 1 : zcap);
                         uint32_t e; int ri;
-                        classify(32 * w + 31 - i, z, e, ri);
+                        classify(r0 - i, z, e, ri);
                         const uint32_t t = ring[ri & (GW_RING - 1)];
-                        ring[(32 * w + 31 - i - cs) & (GW_RING - 1)] = (unsigned short)finish(e, ri, t);
+                        ring[(r0 - i) & (GW_RING - 1)] = (unsigned short)finish(e, ri, t);
                     }
                 }
             }
