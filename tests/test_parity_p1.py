@@ -281,6 +281,33 @@ def test_golomb_random_round_trip_and_decoder_end_conditions(be):
         assert np.array_equal(dq[i].reshape(-1), _pad(wq.astype(np.int64), N * C)), i
 
 
+def test_golomb_streams_that_do_not_fall_into_step(be):
+    """The wave-per-frame decoder guesses where each lane's chunk of the stream begins and corrects the guesses from the left;
+    equal-length codes keep a wrongly started walk out of step for ever, so these streams take the most rounds (and, beyond
+    its round limit, the lane-per-frame kernel): k = 3, one 6-bit code, then 4-bit codes only -- every chunk is entered at
+    offset 2 (mod 4), never at the guessed 0.  Also a stream whose second half is in step and one of 2-bit codes."""
+    N, C = (640, 2) if be.name == "emu" else (2048, 2)
+    tq = np.arange(27 * C, dtype=np.int32).reshape(1, 27, C) % 7
+    tbytes = fo.golomb_encode(tq.reshape(-1))
+
+    def body_of(k, bits):
+        bits = bits + "0" * (-len(bits) % 8)
+        return len(tbytes).to_bytes(4, "big") + tbytes + bytes([k]) + int(bits, 2).to_bytes(len(bits) // 8, "big")
+
+    n = N * C
+    rng = np.random.default_rng(5)
+    tail = "".join("1" + format(int(v), "03b") for v in rng.integers(0, 8, n // 2))
+    bodies = [body_of(3, "010000" + "1111" * (n - 1)),
+              body_of(3, "010000" + "1111" * (n // 2) + "011" + tail),          # (the walk meets a code cut differently half-way)
+              body_of(1, "0100" + "11" * (n - 1)),
+              body_of(3, "010000" + "1010" * (n // 3))]                          # ends early: the rest of the frame is zero
+    dq, dt, st = be.golomb_decode(bodies, N, C)
+    for i, b in enumerate(bodies):
+        wq = fo.golomb_decode(b[4 + len(tbytes):])[:n]
+        assert np.array_equal(dq[i].reshape(-1), _pad(np.asarray(wq, np.int64), n)), i
+        assert np.array_equal(dt[i], tq[0]), i
+
+
 def test_golomb_decoder_on_damaged_streams(be):
     """Random bit flips and zero runs inside valid bodies: long codes (> 64 bits), spurious early ends, values beyond
     int32 -- the wave-per-frame decoder must hand what it cannot take to the lane-per-frame one, and both must agree with
