@@ -10,9 +10,9 @@
 // With k taken from the maximum, z + 2^k < 2^(k+2): every value costs k + 1 or k + 3 bits, so a frame's worst case is
 // known up front (frad_p1_golomb_bound) and the coder needs no second look at the data.
 //
-//   k_gol_encode   one 256-thread block per frame: |max| reduction -> k, per-thread code lengths of 16 consecutive
-//                  values -> block scan -> bit offsets -> codes OR-ed into an LDS word buffer -> big-endian words out.
-//                  Frames longer than a tile (4096 values) carry the partial last word into the next tile.
+//   k_gol_encode   one WAVE per frame: |max| reduction -> k, per-lane code lengths of 16 consecutive values -> wave scan
+//                  -> bit offsets -> every lane packs its stretch into whole words and ORs them into an LDS word buffer ->
+//                  big-endian words out.  A tile is 1024 values; the partial last word is carried into the next tile.
 //   k_rows_scan / k_rows_gather   exclusive scan of the body lengths and a gather into one contiguous buffer, so
 //                  that a batch goes back to the host (zlib) as ONE copy of exactly the bytes it needs.
 //   k_gol_decode   one LANE per frame (thresholds, then coefficients): the code boundaries of a prefix code are a
@@ -26,47 +26,16 @@
 namespace frad {
 namespace {
 
-constexpr int GT = 256;                    // threads per encode block
-constexpr int GV = 16;                     // consecutive values per thread and tile
-constexpr int GTILE = GT * GV;             // values per tile
-constexpr int GWORDS = (GTILE * 35 + 31) / 32 + 4;     // 32-bit words a tile can fill (<= 35 bits per value) + carry
-constexpr int GOL_LDS = GWORDS * 4 + GT * 8;
+constexpr int GT = 256;                    // threads of the row scan / gather blocks
+constexpr int GV = 16;                     // consecutive values per lane and tile
+constexpr int WTILE = 64 * GV;             // values per tile of the coder (one wave)
+constexpr int GWORDS = (WTILE * 35 + 31) / 32 + 4;     // 32-bit words a tile can fill (<= 35 bits per value) + carry
+constexpr int GOL_LDS = GWORDS * 4;
 
 __device__ __forceinline__ int bitlen64(u64 v) { return v ? 64 - __builtin_clzll(v) : 0; }
 __device__ __forceinline__ u64 zigzag(int32_t v) { return v > 0 ? 2ull * (u64)v - 1ull : 2ull * (u64)(-(long long)v); }
 // k = ceil(log2(dmax)) for dmax >= 1 (numpy evaluates it in float64, exact for |v| < 2^53), 0 for dmax = 0
 __device__ __forceinline__ int rice_k(u64 dmax) { return dmax <= 1 ? 0 : bitlen64(dmax - 1); }
-
-struct BitSink {                           // the body as ONE bit sequence; LDS words hold bits [base, base + 32 * GWORDS)
-    int* words;                            // LDS, MSB-first inside a word
-    unsigned char* out;                    // the frame's row (4-byte aligned)
-    long long base;                        // bit position of words[0], a multiple of 32
-};
-
-// OR `nbits` (<= 64) bits of `code` into the sink at absolute bit position `pos`
-__device__ __forceinline__ void sink_put(const BitSink& s, long long pos, u64 code, int nbits) {
-    int rel = (int)(pos - s.base);
-    while (nbits > 0) {
-        const int w = rel >> 5, off = rel & 31, room = 32 - off;
-        const int take = nbits < room ? nbits : room;
-        const uint32_t piece = (uint32_t)((code >> (nbits - take)) & ((take == 32) ? 0xffffffffull : ((1ull << take) - 1ull)));
-        atomicOr(&s.words[w], (int)(piece << (room - take)));
-        rel += take; nbits -= take;
-    }
-}
-// store the complete words below `pos`, keep the partial one as word 0 of the next stretch; block-wide
-__device__ __forceinline__ void sink_flush(BitSink& s, long long pos, bool final_) {
-    __syncthreads();
-    const int full = (int)((pos - s.base) >> 5), part = (int)((pos - s.base) & 31);
-    const int n = final_ && part ? full + 1 : full;
-    uint32_t* dst = reinterpret_cast<uint32_t*>(s.out + (s.base >> 3));
-    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = bswap32((uint32_t)s.words[i]);
-    const int carry = part ? s.words[full] : 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < GWORDS; i += blockDim.x) s.words[i] = (i == 0) ? carry : 0;
-    s.base += (long long)full * 32;
-    __syncthreads();
-}
 
 // block-wide inclusive scan of one int per thread (GT threads); returns this thread's inclusive sum, *total = block sum
 __device__ __forceinline__ long long block_scan(long long v, long long* tmp, long long* total) {
@@ -83,61 +52,112 @@ __device__ __forceinline__ long long block_scan(long long v, long long* tmp, lon
     __syncthreads();
     return r;
 }
-__device__ __forceinline__ u64 block_max(u64 v, u64* tmp) {
-    v = wave_max_u64(v);
-    if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = v;
-    __syncthreads();
-    u64 r = 0;
-    for (int i = 0; i < GT / 64; ++i) r = tmp[i] > r ? tmp[i] : r;
-    __syncthreads();
-    return r;
+// ---- encode, one WAVE per frame ------------------------------------------------------------------------------------------
+// The body is ONE bit sequence.  A tile is 64 lanes x 16 consecutive values; a lane's codes are contiguous in the stream, so
+// it packs them into whole 32-bit words in registers (MSB first) and ORs only those into the LDS word buffer -- the first and
+// the last word of its stretch are shared with its neighbours.  Bit offsets: a wave scan of the lanes' code lengths (no block
+// barrier anywhere).  After a tile the complete words leave as big-endian words (coalesced) and are zeroed in the same
+// sweep; the partial last word stays as word 0 of the next tile.
+struct WaveSink {
+    int* words;                            // LDS, bits [base, base + 32 * GWORDS), MSB-first inside a word; all zero between tiles
+    unsigned char* out;                    // the frame's row (4-byte aligned)
+    long long base;                        // bit position of words[0], a multiple of 32
+};
+// the complete words below `pos` go out (with the partial one when `final_`), the partial one becomes word 0; wave-wide
+__device__ __forceinline__ void wsink_flush(WaveSink& s, long long pos, bool final_) {
+    FRAD_LDS_BARRIER();
+    const int lane = threadIdx.x & 63;
+    const int full = (int)((pos - s.base) >> 5), part = (int)((pos - s.base) & 31);
+    const int n = final_ && part ? full + 1 : full;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s.out + (s.base >> 3));
+    const int carry = part && !final_ ? s.words[full] : 0;
+    FRAD_LDS_BARRIER();                                       // (every lane has read the carry word before it is cleared)
+    for (int i = lane; i <= full; i += 64) {
+        const uint32_t v = (uint32_t)s.words[i];
+        s.words[i] = (i == 0) ? carry : 0;
+        if (i < n) dst[i] = bswap32(v);
+    }
+    s.base += (long long)full * 32;
+    FRAD_LDS_BARRIER();
 }
+// one lane's stretch of the stream: bits are appended to a 64-bit accumulator whose top `nacc` (< 32) bits are taken
+struct LaneBits {
+    u64 acc; int nacc, w;
+    __device__ __forceinline__ void put(int* words, uint32_t bits, int nb) {          // nb <= 32 bits, `bits` < 2^nb
+        if (nb <= 0) return;
+        acc |= (u64)bits << (64 - nacc - nb);
+        nacc += nb;
+        if (nacc >= 32) { atomicOr(&words[w], (int)(uint32_t)(acc >> 32)); acc <<= 32; nacc -= 32; ++w; }
+    }
+    __device__ __forceinline__ void done(int* words) { if (nacc > 0 && (uint32_t)(acc >> 32)) atomicOr(&words[w], (int)(uint32_t)(acc >> 32)); }
+};
 
 // one stream (n values at `data`) appended at bit position `pos` (byte aligned): k byte + codes + zero padding
-__device__ __forceinline__ long long encode_stream(BitSink& s, long long pos, const int32_t* __restrict__ data, long long n, long long* tmp) {
+__device__ __forceinline__ long long encode_stream_wave(WaveSink& s, long long pos, const int32_t* __restrict__ data, long long n) {
+    const int lane = threadIdx.x & 63;
     u64 dmax = 0;
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) { const long long v = data[i]; const u64 a = (u64)(v < 0 ? -v : v); dmax = a > dmax ? a : dmax; }
-    dmax = block_max(dmax, reinterpret_cast<u64*>(tmp));
+    for (long long i = lane; i < n; i += 64) { const long long v = data[i]; const u64 a = (u64)(v < 0 ? -v : v); dmax = a > dmax ? a : dmax; }
+    dmax = wave_max_u64(dmax);
     const int k = rice_k(dmax);
-    if (threadIdx.x == 0) sink_put(s, pos, (u64)k, 8);
+    if (lane == 0) atomicOr(&s.words[(int)((pos - s.base) >> 5)], (int)((uint32_t)k << (24 - (int)((pos - s.base) & 31))));   // pos is byte aligned
     pos += 8;
-    for (long long t0 = 0; t0 < n; t0 += GTILE) {
-        const long long j0 = t0 + (long long)threadIdx.x * GV;
-        u64 code[GV]; int len[GV]; long long mine = 0;
+    const bool vec = (reinterpret_cast<uintptr_t>(data) & 15) == 0;
+    for (long long t0 = 0; t0 < n; t0 += WTILE) {
+        const long long j0 = t0 + (long long)lane * GV;
+        int32_t v[GV];
+        if (vec && j0 + GV <= n) {
+#pragma unroll
+            for (int i = 0; i < GV; i += 4) {
+                const v4u q4 = *FRAD_GCPTR(v4u, data + j0 + i);
+                v[i] = (int32_t)q4[0]; v[i + 1] = (int32_t)q4[1]; v[i + 2] = (int32_t)q4[2]; v[i + 3] = (int32_t)q4[3];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < GV; ++i) v[i] = j0 + i < n ? data[j0 + i] : 0;
+        }
+        u64 code[GV]; int mine = 0;
 #pragma unroll
         for (int i = 0; i < GV; ++i) {
-            len[i] = 0; code[i] = 0;
+            code[i] = zigzag(v[i]) + (1ull << k);
+            // m = L - (k + 1) zeros, then the L-bit number, L = k + 1 or k + 2: k + 1 or k + 3 bits
+            mine += j0 + i < n ? ((code[i] >> (k + 1)) ? k + 3 : k + 1) : 0;
+        }
+        int incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = (int)__shfl((unsigned long long)(unsigned)incl, lane >= off ? lane - off : lane, 64);
+            incl += lane >= off ? o : 0;
+        }
+        const int total = (int)__shfl((unsigned long long)(unsigned)incl, 63, 64);
+        const int rel = (int)(pos - s.base) + incl - mine;
+        LaneBits lb{0, rel & 31, rel >> 5};
+#pragma unroll
+        for (int i = 0; i < GV; ++i) {
             if (j0 + i < n) {
-                code[i] = zigzag(data[j0 + i]) + (1ull << k);
-                const int L = bitlen64(code[i]);
-                len[i] = 2 * L - (k + 1);                      // m = L - (k + 1) zeros, then the L-bit number
-                mine += len[i];
+                const int len = (code[i] >> (k + 1)) ? k + 3 : k + 1;
+                if (len > 32) { lb.put(s.words, (uint32_t)(code[i] >> 32), len - 32); lb.put(s.words, (uint32_t)code[i], 32); }
+                else lb.put(s.words, (uint32_t)code[i], len);
             }
         }
-        long long total;
-        long long at = pos + block_scan(mine, tmp, &total) - mine;
-#pragma unroll
-        for (int i = 0; i < GV; ++i) if (len[i]) { sink_put(s, at, code[i], len[i]); at += len[i]; }
+        lb.done(s.words);
         pos += total;
-        sink_flush(s, pos, false);
+        wsink_flush(s, pos, false);
     }
     return (pos + 7) & ~7LL;                                   // bitstr2bytes pads with zeros
 }
 
-__global__ void __launch_bounds__(GT) k_gol_encode(const int32_t* __restrict__ q, const int32_t* __restrict__ tq, long long nq, long long ntq,
+__global__ void __launch_bounds__(64) k_gol_encode(const int32_t* __restrict__ q, const int32_t* __restrict__ tq, long long nq, long long ntq,
                                                    unsigned char* __restrict__ body, long long stride, long long* __restrict__ nbytes) {
-    FRAD_DYN_SMEM(smem);                                      // GOL_LDS bytes: the word buffer, then the scan scratch
+    FRAD_DYN_SMEM(smem);                                      // GOL_LDS bytes: the word buffer
     int* words = reinterpret_cast<int*>(smem);
-    long long* tmp = reinterpret_cast<long long*>(smem + GWORDS * 4);
     const long long f = blockIdx.x;
-    BitSink s{words, body + f * stride, 0};
-    for (int i = threadIdx.x; i < GWORDS; i += blockDim.x) words[i] = 0;
-    __syncthreads();
+    WaveSink s{words, body + f * stride, 0};
+    for (int i = threadIdx.x; i < GWORDS; i += 64) words[i] = 0;
+    FRAD_LDS_BARRIER();
     // '>I' len(thres_gol) is only known once that stream is coded: it goes first, so code the thresholds from bit 32
-    // on and patch the length in afterwards (the words of the first tile are still in LDS or already stored)
-    const long long end_t = encode_stream(s, 32, tq + f * ntq, ntq, tmp);
-    const long long end_q = encode_stream(s, end_t, q + f * nq, nq, tmp);
-    sink_flush(s, end_q, true);
+    // on and patch the length in afterwards (the first word has left LDS by then)
+    const long long end_t = encode_stream_wave(s, 32, tq + f * ntq, ntq);
+    const long long end_q = encode_stream_wave(s, end_t, q + f * nq, nq);
+    wsink_flush(s, end_q, true);
     if (threadIdx.x == 0) {
         const uint32_t tlen = (uint32_t)((end_t - 32) >> 3);
         *reinterpret_cast<uint32_t*>(s.out) = bswap32(tlen);
@@ -153,11 +173,27 @@ __global__ void __launch_bounds__(GT) k_rows_scan(const long long* __restrict__ 
     const long long per = (n + GT - 1) / GT;
     const long long a = (long long)threadIdx.x * per, e = a + per < n ? a + per : n;
     long long mine = 0;
-    for (long long i = a; i < e; ++i) mine += nbytes[i];
+    long long i = a;
+    for (; i + 8 <= e; i += 8) {                                  // eight loads in flight (a thread's run is one dependent chain otherwise)
+        long long v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = nbytes[i + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mine += v[j];
+    }
+    for (; i < e; ++i) mine += nbytes[i];
     long long total;
     long long run = block_scan(mine, tmp, &total) - mine;        // sum of all rows before this thread's run
     if (threadIdx.x == 0) offsets[0] = 0;
-    for (long long i = a; i < e; ++i) { run += nbytes[i]; offsets[i + 1] = run; }
+    i = a;
+    for (; i + 8 <= e; i += 8) {
+        long long v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = nbytes[i + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { run += v[j]; offsets[i + j + 1] = run; }
+    }
+    for (; i < e; ++i) { run += nbytes[i]; offsets[i + 1] = run; }
 }
 __global__ void __launch_bounds__(GT) k_rows_gather(const unsigned char* __restrict__ rows, long long stride, const long long* __restrict__ offsets,
                                                     unsigned char* __restrict__ out) {
@@ -549,7 +585,7 @@ int frad_p1_golomb_encode(const int32_t* q, const int32_t* tq, int64_t n_frames,
     if (!q || !tq || !bodies || !body_bytes) return FRAD_E_INVALID;
     if (body_stride < (int64_t)frad_p1_golomb_bound(N, C) || (body_stride & 3) || (reinterpret_cast<uintptr_t>(bodies) & 3)) return FRAD_E_INVALID;
     if (n_frames > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
-    hipLaunchKernelGGL(k_gol_encode, dim3((unsigned)n_frames), dim3(GT), GOL_LDS, static_cast<hipStream_t>(stream), q, tq, (long long)N * C, 27LL * C,
+    hipLaunchKernelGGL(k_gol_encode, dim3((unsigned)n_frames), dim3(64), GOL_LDS, static_cast<hipStream_t>(stream), q, tq, (long long)N * C, 27LL * C,
                        static_cast<unsigned char*>(bodies), (long long)body_stride, reinterpret_cast<long long*>(body_bytes));
     GOLCHK(hipGetLastError());
     return FRAD_OK;
