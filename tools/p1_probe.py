@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Profile-1 kernel probe (cfg 5 geometry: N = 2048 stereo s16, hop 1920): K7 / K8 time for a 60 s and a 10 min clip.
-FRAD_TUNE_NO_WAVE_P1=1 selects the one-shot kernels for comparison."""
+FRAD_TUNE_NO_WAVE_P1=1 selects the one-shot kernels for comparison.
+
+Last line: the UNFUSED yardstick of K7, as a lower bound built from parts that exist: (A) the profile-0 wave
+encode of the same frames at 64-bit little-endian storage -- the same DCT, its coefficients to an HBM plane --, measured, plus
+(B) a streaming quantiser priced at nothing but its bytes (coefficient plane in, q + tq out) moved at the speed of the
+hand-written copy kernel, measured here on the same byte count.  A real (B) also has K7's 2 500 instructions per frame."""
 import json, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,3 +34,14 @@ for secs in (60, 600):
     print(json.dumps({"secs": secs, "frames": F, "wave": not os.environ.get("FRAD_TUNE_NO_WAVE_P1"),
                       "K7_ms": round(t7, 4), "K7_frac": round(b7 / t7 / 1e6 / 8000, 4),
                       "K8_ms": round(t8, 4), "K8_frac": round(b8 / t8 / 1e6 / 8000, 4)}))
+    if secs == 600:
+        out = torch.empty((F, N * C * 8), dtype=torch.uint8, device=dev)
+        am = torch.empty(F, dtype=torch.float64, device=dev)
+        ta = timeit(lambda: core.analogue_batch(0, pcm, "s16le", F, N, C, 64, True, frame_stride=hop, check_overflow=False, out=out, absmax=am))
+        lib = _lib.load()
+        nb = F * (N * C * 8 + N * C * 4 + 27 * C * 4) // 2 // 16 * 16          # a copy moves every byte twice (read + write)
+        src = torch.empty(nb, dtype=torch.uint8, device=dev); dst = torch.empty_like(src)
+        st = int(torch.cuda.current_stream().cuda_stream)
+        tb = timeit(lambda: lib.bench_copy(src.data_ptr(), dst.data_ptr(), nb, st))
+        print(json.dumps({"secs": secs, "frames": F, "K7_unfused_lower_bound_ms": round(ta + tb, 4), "A_p0_encode_64bit_ms": round(ta, 4),
+                          "B_bytes_only_ms": round(tb, 4), "B_bytes": 2 * nb, "K7_fused_ms": round(t7, 4)}))
