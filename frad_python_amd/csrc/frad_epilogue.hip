@@ -10,6 +10,7 @@
 //   k_from_f64        float64 [n] -> any of the 20 PCM formats; fused into the profile-4 unpack (k_p4_unpack_pcm).
 //   frad_asfh_scan    host code: walks a FrAD byte stream once and fills a table of frames (tools/asfh.py:98-134,
 //                     decoder.py:82-106) so that the Python decoder no longer parses headers frame by frame.
+#include <atomic>
 #include "frad_p1.hpp"
 #include "frad_launch.hpp"
 #include "../../include/frad_hip.h"
@@ -163,6 +164,10 @@ struct Scratch {                                               // stream-ordered
 
 using namespace frad;
 
+// calls of frad_p{0,1}_digital_pcm that took the float64 scratch + second pass (diagnostic: tests assert which geometries still do)
+static std::atomic<long long> g_second_passes{0};
+extern "C" long long frad_debug_second_passes(void) { return g_second_passes.load(std::memory_order_relaxed); }
+
 extern "C" {
 
 int frad_from_f64(const double* pcm, int64_t n_values, int32_t out_dtype, uint32_t flags, void* out, void* stream) {
@@ -217,6 +222,7 @@ int frad_p0_digital_pcm(const void* payload, int64_t payload_stride, int64_t n_f
         const int r = p0_digital_out(payload, payload_stride, n_frames, N, C, bits, flags, out_dtype, pcm_out, stream);
         if (r != 1) return r;
     }
+    g_second_passes.fetch_add(1, std::memory_order_relaxed);
     Scratch ws(s);
     const size_t n = (size_t)n_frames * N * C;
     if (hipMallocAsync(&ws.p, n * 8, s) != hipSuccess) return FRAD_E_NOMEM;
@@ -236,6 +242,7 @@ int frad_p1_digital_pcm(const int32_t* q, const int32_t* tq, int64_t n_frames, i
         const int r = p1_digital_out(q, tq, n_frames, N, C, bits, srate, out_dtype, flags, pcm_out, stream);   // one pass where the kernel's store converts
         if (r != 1) return r;
     }
+    g_second_passes.fetch_add(1, std::memory_order_relaxed);
     Scratch ws(s);
     const size_t n = (size_t)n_frames * N * C;
     if (hipMallocAsync(&ws.p, n * 8, s) != hipSuccess) return FRAD_E_NOMEM;

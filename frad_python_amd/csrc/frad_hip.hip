@@ -563,10 +563,16 @@ int p0_digital_impl(const void* payload, int64_t payload_stride, int64_t n_frame
         if (c.cg == C && ai && C <= 2 && ((long long)N * C) % 32 == 0) g.cc_fast = C;
         if (!conv && c.cg == C && C <= 2 && aligned16(pcm_out)) g.in_mode = C;      // decode: quad store for C = 1 / 2
         dim3 grid((unsigned)((n_frames + c.fpb - 1) / c.fpb));
-        if (conv) {                                          // the kernels whose store converts: one-shot / channel-group
-            // only where frad_p0_digital runs them too (the result must equal from_f64 of ITS samples bit for bit): not the
-            // wave / unit kernels' geometries (N = 1024 / 2048 with 1-2 channels), not the two-pass whole-row kernels'
-            if (((c.log2m == 9 || c.log2m == 10) && C <= 2) || (c.cg < C && C == 2 * c.cg)) return 1;
+        if (conv) {
+            // every store converts, and the kernel is the one frad_p0_digital would run on an aligned float64 buffer (the result
+            // must equal from_f64 of ITS samples bit for bit).  Only the wave kernel's geometries are left to the caller: its
+            // converting twin (k_p0_inv_wave_pcm: s16 / s32 / f32) was tried first, the other formats take the second pass.
+            if ((c.log2m == 9 || c.log2m == 10) && C <= 2) {
+                if (p0_inv_wave_takes(g, ai, unit_neg)) return 1;
+                if (c.cg == C) g.in_mode = C;                 // (what the float64 path sets for an aligned buffer: the unit kernels ask for it)
+                if (launch_p0_inv_pers(c, s, in, pcm_out, tb, g)) { HIPCHK(hipGetLastError()); return FRAD_OK; }
+                g.in_mode = 0;
+            } else if (c.cg < C && launch_p0_inv_grp2(c, s, in, pcm_out, tb, g)) { HIPCHK(hipGetLastError()); return FRAD_OK; }
             rc = launch_p0_inv(c, grid, s, in, pcm_out, tb, g, ai);
             if (rc != FRAD_OK) return rc;
         } else if (c.cg < C && launch_p0_inv_grp2(c, s, in, pcm_out, tb, g)) {

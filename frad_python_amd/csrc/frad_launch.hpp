@@ -93,6 +93,7 @@ int mixed_last_hip_error();
 // wave-autonomous kernels for N = 2048, C <= 2, 16/32/64-bit storage (frad_p0_wave.hip): 1 = launched, 0 = not applicable
 int launch_p0_fwd_wave(int lg, hipStream_t s, const unsigned char* pcm, unsigned char* pay, double* absmax, const Geom& g,
                        int aligned_in, int aligned_out, unit_root_fn unit);
+bool p0_inv_wave_takes(const Geom& g, int aligned_in, unit_root_fn unit);
 int launch_p0_inv_wave(hipStream_t s, const unsigned char* pay, double* out, const Geom& g, int aligned_in, int aligned_out,
                        unit_root_fn unit);
 struct P1Wave;

@@ -31,7 +31,9 @@ __device__ __forceinline__ double piece_value(const uint32_t (&w)[NW], int v, bo
     return code_to_f64(c, BITS);
 }
 
-template <int LOG2M, int CG, int BITS, int NH = 1>
+// CONV: the samples leave in the caller's PCM format (Geom::dtype) -- an instantiation of its own, so that the float64 kernel of
+// the BASELINE path keeps its registers (the converting store as a run-time branch cost it 164 B of scratch per lane)
+template <int LOG2M, int CG, int BITS, int NH = 1, bool CONV = false>
 __global__ void __launch_bounds__(CG * Plan<LOG2M>::TEAM, NH)   // NH = 2: 256 threads, two blocks per CU -> 2 waves per SIMD
 k_p0_inv_grp2(const unsigned char* __restrict__ payload, double* __restrict__ out,
               const cx<double>* __restrict__ tw, const cx<double>* __restrict__ post, Geom g) {
@@ -95,6 +97,24 @@ k_p0_inv_grp2(const unsigned char* __restrict__ payload, double* __restrict__ ou
     fft_team<double, LOG2M, true>(buf, tt, tw);
 #endif
     __syncthreads();
+    if constexpr (CONV) {                                     // the caller's PCM format instead of float64 (frad_p0_digital_pcm;
+        dispatch_out_format(g.dtype, [&](auto kind_tag, auto lg_tag) {            //  backend/pcmformat.py:49-62 applied in the store)
+            constexpr int KIND = decltype(kind_tag)::value, LGS = decltype(lg_tag)::value;
+            const bool be = (g.dtype & 1) != 0, raw = g.raw_be != 0 && be;
+            unsigned char* dstb = reinterpret_cast<unsigned char*>(out) + ((f * (long long)N * C + part * (2 * CG)) << LGS);
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int n = threadIdx.x + i * T, m = makhoul(n, N);
+                unsigned char* row = dstb + (((long long)n * C) << LGS);
+#pragma unroll
+                for (int j = 0; j < CG; ++j) {
+                    store_pcm_elem<LGS>(row + (j << LGS), from_f64_bits<KIND, LGS>(res[i][j], raw), be);
+                    store_pcm_elem<LGS>(row + ((CG + j) << LGS), from_f64_bits<KIND, LGS>(xslot<double, SH>(smem, j, SLOTS, m), raw), be);
+                }
+            }
+        });
+        return;
+    }
     double* dst = out + f * (long long)N * C + part * (2 * CG);
 #pragma unroll
     for (int i = 0; i < RPT; ++i) {
@@ -191,8 +211,10 @@ template <int LOG2M, int CG, int NH = 1>
 int go_grp2(int bits, size_t lds, dim3 grid, int pipe_grid, hipStream_t s, const unsigned char* pay, double* out,
             const cx<double>* tw, const cx<double>* post, const Geom& g) {
     constexpr int T = CG * Plan<LOG2M>::TEAM;
-#define GO(B) do { allow_lds(k_p0_inv_grp2<LOG2M, CG, B, NH>, lds); \
-        hipLaunchKernelGGL((k_p0_inv_grp2<LOG2M, CG, B, NH>), grid, dim3(T), lds, s, pay, out, tw, post, g); } while (0)
+#define GO(B) do { if (g.dtype != 22) { allow_lds(k_p0_inv_grp2<LOG2M, CG, B, NH, true>, lds); \
+        hipLaunchKernelGGL((k_p0_inv_grp2<LOG2M, CG, B, NH, true>), grid, dim3(T), lds, s, pay, out, tw, post, g); } else { \
+        allow_lds(k_p0_inv_grp2<LOG2M, CG, B, NH>, lds); \
+        hipLaunchKernelGGL((k_p0_inv_grp2<LOG2M, CG, B, NH>), grid, dim3(T), lds, s, pay, out, tw, post, g); } } while (0)
     if constexpr (CG >= 2 && NH == 1) {
         if (pipe_grid > 0) {
 #define GOP(B) do { allow_lds(k_p0_inv_grp2p<LOG2M, CG, B>, lds); \
@@ -215,13 +237,14 @@ int go_grp2(int bits, size_t lds, dim3 grid, int pipe_grid, hipStream_t s, const
 int launch_p0_inv_grp2(const FastCfg& c, hipStream_t s, const unsigned char* pay, double* out, const Tables& tb, const Geom& g) {
     if (tune("FRAD_TUNE_NO_GRP2")) return 0;                                       // A/B knob, not part of the ABI
     if (g.C != 2 * c.cg || g.n_frames > 0x7fffffffLL) return 0;
-    if ((reinterpret_cast<uintptr_t>(pay) & 15) || (g.payload_stride & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return 0;
+    const bool conv = g.dtype != 22;                          // not FRAD_PCM_F64LE: the store converts (element stores: no alignment asked of `out`)
+    if ((reinterpret_cast<uintptr_t>(pay) & 15) || (g.payload_stride & 15) || (!conv && (reinterpret_cast<uintptr_t>(out) & 15))) return 0;
     const cx<double>* tw = static_cast<const cx<double>*>(tb.tw);
     const cx<double>* post = static_cast<const cx<double>*>(tb.post);
     dim3 grid((unsigned)g.n_frames);
     // persistent pipelined variant: one block per CU, each walking frames blockIdx.x, + grid, ...
     int pipe = 0;
-    if (tune("FRAD_TUNE_GRP2_PIPE")) { const int cus = grp2_cu_count(); pipe = (int)(g.n_frames < cus ? g.n_frames : cus); }
+    if (!conv && tune("FRAD_TUNE_GRP2_PIPE")) { const int cus = grp2_cu_count(); pipe = (int)(g.n_frames < cus ? g.n_frames : cus); }
     // Two half-size blocks per frame (2 x CG/2 channels each), two blocks resident per CU: one block's loads and stores
     // run under the other's transforms (a single block serialises them: cfg 4, N = 4096 x 8 channels, 0.53 -> 0.45 ms)
     if (!tune("FRAD_TUNE_GRP2_WHOLE")) {

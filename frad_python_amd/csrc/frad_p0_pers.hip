@@ -246,6 +246,7 @@ int launch_p0_inv_pers(const FastCfg& c, hipStream_t s, const unsigned char* pay
         }
         return 1;
     }
+    if (g.dtype != 22) return 0;                              // (not FRAD_PCM_F64LE; only the unit kernels' store converts: frad_p0_digital_pcm)
     const bool pb = plan_b() && tb.blob_b != nullptr && g.bits != 12;   // a 12-bit unit is wider than plan B's lane share
     const int teams = 8, team = pb ? PlanB10::TEAM : PlanA10::TEAM;
     g.fpb = teams / g.C;

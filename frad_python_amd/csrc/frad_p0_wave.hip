@@ -161,6 +161,12 @@ int launch_p0_fwd_wave(int lg, hipStream_t s, const unsigned char* pcm, unsigned
     return 1;
 }
 
+// would launch_p0_inv_wave take this batch into an aligned float64 buffer?  (frad_p0_digital_pcm must convert the samples of the
+// kernel frad_p0_digital runs)
+bool p0_inv_wave_takes(const Geom& g, int ai, unit_root_fn unit) {
+    return !wave_disabled() && wave_geometry(g.N, g.C, g.bits) && ai && !tune("FRAD_TUNE_NO_WAVE_DEC") && wave_blob(unit) != nullptr;
+}
+
 int launch_p0_inv_wave(hipStream_t s, const unsigned char* pay, double* out, const Geom& g, int ai, int ao, unit_root_fn unit) {
     if (wave_disabled() || !wave_geometry(g.N, g.C, g.bits) || !ai || !ao) return 0;
     if (tune("FRAD_TUNE_NO_WAVE_DEC")) return 0;

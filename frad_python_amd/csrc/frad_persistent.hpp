@@ -715,6 +715,31 @@ __device__ FRAD_NOINLINE void store_frame_rows(int data_off, double* __restrict_
     }
 }
 
+// The same rows leaving in the caller's PCM format (frad_p0_digital_pcm: backend/pcmformat.py:49-62 applied in the store; Geom::dtype
+// names the format): a lane converts its row's CC samples, so a wave still writes one contiguous stretch per instruction.
+template <int SH, int CC, int M>
+__device__ FRAD_NOINLINE void store_frame_rows_pcm(int data_off, unsigned char* __restrict__ dstf, int utid, int dtype, int raw_be) {
+    FRAD_DYN_SMEM(smem);
+    const double* data = reinterpret_cast<const double*>(smem + data_off);
+    constexpr int N = 2 * M, uth = CC * 64;
+    auto sample = [&](int c, int n) -> double {
+        const int q = n >> 2, r = n & 3;
+        const int slot = (r & 1) ? (M - 1 - q) : q;
+        return data[((long long)c * M + phys<double, SH>(slot)) * 2 + ((r == 1) | (r == 2))];
+    };
+    dispatch_out_format(dtype, [&](auto kind_tag, auto lg_tag) {
+        constexpr int KIND = decltype(kind_tag)::value, LGS = decltype(lg_tag)::value;
+        const bool be = (dtype & 1) != 0, raw = raw_be != 0 && be;
+#pragma unroll 4
+        for (int i = 0; i < N / uth; ++i) {
+            const int n = utid + i * uth;
+#pragma unroll
+            for (int c = 0; c < CC; ++c)
+                store_pcm_elem<LGS>(dstf + (((long long)n * CC + c) << LGS), from_f64_bits<KIND, LGS>(sample(c, n), raw), be);
+        }
+    });
+}
+
 template <typename PL, int BITS, int CC>
 __global__ void __launch_bounds__(512, UnitWaves<PL>::value)
 k_p0_inv_unit(const unsigned char* __restrict__ payload, double* __restrict__ out, const cx<double>* __restrict__ blob, Geom g) {
@@ -800,6 +825,10 @@ k_p0_inv_unit(const unsigned char* __restrict__ payload, double* __restrict__ ou
 #pragma unroll
                 for (int j = 0; j < UB / 4; ++j) FRAD_OPAQUE(pf[i][w][j]);
         unit_barrier<CC>(ctr, epoch);
+        if (g.dtype != 22) {                                  // (uniform) the caller's PCM format instead of float64
+            const int lgs = (g.dtype >> 1) & 3;
+            store_frame_rows_pcm<SH, CC, M>(data_off, reinterpret_cast<unsigned char*>(out) + ((f * (long long)N * CC) << lgs), utid, g.dtype, g.raw_be);
+        } else
         store_frame_rows<SH, CC, M>(data_off, out + f * (long long)N * CC, utid);
         unit_barrier<CC>(ctr, epoch);
         f = next;

@@ -59,7 +59,7 @@ def test_baseline_path_kernels_keep_their_registers():
     zero = ["k_p0_fwd_wave<1, 2, 32, false>", "k_p0_inv_wave<2, 32, false>",          # cfg 2 full frames
             "k_p0_fwd_wave<1, 2, 32, true>", "k_p0_inv_wave<2, 32, true>",            # cfg 3 full frames (clip batch, in place)
             "k_p0_fwd_unit<double, PlanA9, 1, 2>", "k_p0_inv_unit<PlanA9, 32, 2>",   # cfg 2's 1024-sample tail
-            "k_p0_fwd_half32<11, 4, 32>", "k_p0_inv_grp2<11, 2, 32, 2>",             # cfg 4
+            "k_p0_fwd_half32<11, 4, 32>", "k_p0_inv_grp2<11, 2, 32, 2, false>",      # cfg 4
             "k_p1_inv_wave<2>", "k_p1_ola<0>", "k_gol_decode_wave", "k_gol_encode"]   # cfg 5 (decode side, entropy stage)
     for name in zero:
         hit = [k for k in rows if k.endswith(name) or name in k]

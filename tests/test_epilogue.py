@@ -115,6 +115,47 @@ def test_decode_with_conversion_in_the_kernels_own_store(be, geom, fmt):
         assert got.tobytes() == want.tobytes(), ("p1", N, C, fmt)
 
 
+def test_which_geometries_still_take_a_second_pass(be):
+    """frad_p0_digital_pcm / frad_p1_digital_pcm convert in the transform kernel's own store -- no float64 scratch, no
+    second pass -- at N = 1024 (unit kernel) and N = 4096 (two-pass whole-row kernel) as everywhere else below the CU-wide frames; what
+    is left: the N = 2048 wave kernel's geometries with an output format other than s16le / s32le / f32le, profile 1 at N = 2048
+    (K8 writes float64 for the overlap-add, whose own store converts) and frames wider than a CU.  The library counts its
+    second passes (frad_debug_second_passes, not part of the ABI)."""
+    import ctypes
+    if be.name == "emu":
+        dll = be.lib.dll
+    else:
+        from frad_python_amd import _lib
+        dll = _lib.load().dll
+    fn = dll.frad_debug_second_passes
+    fn.restype = ctypes.c_longlong
+    F = 2
+    big = be.name != "emu"
+    cases = [((1024, 2), "s16le", 32, 0), ((1024, 1), "u8", 16, 0), ((1024, 2), "f64be", 24, 0), ((2048, 2), "s16le", 16, 0),
+             ((2048, 2), "u8", 16, 1), ((2048, 2), "s16be", 24, 0), ((896, 2), "s16le", 16, 0), ((300, 3), "s32be", 32, 0)]
+    if big:
+        cases += [((4096, 2), "s16le", 32, 0), ((4096, 8), "s16le", 32, 0), ((4096, 8), "f32le", 16, 0), ((8192, 2), "s16le", 32, 0),
+                  ((28672, 2), "s16le", 32, 1)]
+    for (N, C), fmt, bits, second in cases:
+        raw = synth.to_pcm(synth.harmonic_mix(F * N, C, 48000, seed=N + C), "s16le")
+        frames = [fo.p0_analogue(fo.to_f64(raw[f * N:(f + 1) * N], fo.pcm_dtype("s16le")), bits, 48000, False) for f in range(F)]
+        pay = np.stack([np.frombuffer(fr[0], np.uint8) for fr in frames])
+        before = fn()
+        got = be.digital_pcm(0, pay, F, N, C, bits, False, fmt)
+        assert fn() - before == second, (N, C, fmt, bits)
+        dt = fo.pcm_dtype(fmt)
+        with np.errstate(all="ignore"):
+            want = fo.from_f64(be.digital(0, pay, F, N, C, bits, False), dt).astype(dt)
+        assert got.tobytes() == want.tobytes(), (N, C, fmt, bits)
+    # profile 1: N = 2048 keeps the second pass (K8 -> float64), the other compact sizes do not
+    for N, C, second in ((2048, 2, 1), (1024, 2, 0), (512, 1, 0)) + (((4096, 2, 0),) if big else ()):
+        raw = synth.to_pcm(synth.harmonic_mix(F * N, C, 48000, seed=N), "s16le")
+        q, tq = be.p1_analogue(raw, "s16le", F, N, C, 16, 48000, 0.553)
+        before = fn()
+        be.p1_digital_pcm(q, tq, N, C, 16, 48000, "s16le")
+        assert fn() - before == second, ("p1", N, C)
+
+
 @pytest.mark.parametrize("fmt", ["s16le", "s24le" if False else "s32le", "f32be", "u8", "s16be"])
 def test_overlap_add_with_output_format(be, fmt):
     """frad_p1_overlap_add_pcm == from_f64(frad_p1_overlap_add(...)).astype(fmt) (decoder.py:28-46 then src/decoder.py:23), tail in float64"""

@@ -66,6 +66,20 @@ enc = core.analogue_batch(0, pcm4, "f32le", F, N, C, 32, check_overflow=False)
 o = torch.empty((F, N, C), dtype=torch.float64, device=dev)
 out.append(line("cfg4 p0 encode f32 8ch N=4096 (f32 compute, half-frame blocks)", S * 8, timeit(lambda: core.analogue_batch(0, pcm4, "f32le", F, N, C, 32, check_overflow=False, out=enc.payload, absmax=enc.absmax)), S))
 out.append(line("cfg4 p0 decode (f64, channel-group kernel)", S * 12, timeit(lambda: core.digital_batch(0, enc.payload, F, N, C, 32, out=o)), S))
+for fmt, bo in (("f32le", 4), ("s16le", 2)):               # the conversion in the kernel's own store (no float64 scratch, round 3)
+    on = core._pcm_out_tensor(fmt, (F, N, C), dev)
+    out.append(line(f"cfg4 p0 decode -> {fmt} (converting store)", S * (4 + bo), timeit(lambda: core.digital_batch(0, enc.payload, F, N, C, 32, out=on, out_format=fmt)), S))
+del pcm4, enc, o, on
+# N = 1024 stereo (the unit kernel), 28 126 frames: float64 out and s16 out (converting store)
+F, N, C = 28126, 1024, 2
+S = F * N * C
+pcm1 = (torch.randn((F * N, C), generator=g, device=dev) * 8000).clamp(-32768, 32767).to(torch.int16)
+enc = core.analogue_batch(0, pcm1, "s16le", F, N, C, 32, check_overflow=False)
+o = torch.empty((F, N, C), dtype=torch.float64, device=dev)
+out.append(line("N=1024 stereo p0 decode (f64, unit kernel)", S * 12, timeit(lambda: core.digital_batch(0, enc.payload, F, N, C, 32, out=o)), S))
+on = core._pcm_out_tensor("s16le", (F, N, C), dev)
+out.append(line("N=1024 stereo p0 decode -> s16le (converting store)", S * 6, timeit(lambda: core.digital_batch(0, enc.payload, F, N, C, 32, out=on, out_format="s16le")), S))
+del pcm1, enc, o, on
 # cfg 3: one GPU's share (512) of 4096 x 1 s stereo clips: 23 full frames + an 896-sample tail frame per clip
 clips, n3 = 512, 48000
 full3, tail3 = n3 // 2048, n3 % 2048
