@@ -469,9 +469,15 @@ __device__ __forceinline__ bool decode_stream_2phase(const unsigned char* p, lon
         // walk the codes from chunk-relative position e to the first one that starts beyond the chunk: x = its offset there
         // (< GW_E), GW_END (the stream ended: the last code may be cut short, or only zeros were left) or GW_LONG (a code this
         // path does not take); cnt = codes that start in the chunk.  Selects, not branches: the lanes differ at every step.
-        auto walk = [&](int e, bool act, int& x, int& cnt) {
+        // `lenient`: with the k of the reference coder (taken from the stream's maximum, p1tools.py:47-48) a code has at most ONE
+        // leading zero, so two or more zeros say "this is not a code boundary" and a lenient walk moves on to the next '1' (and
+        // notes that it did).  Without that, a run of equal values -- the zeros of a tonal frame's upper bands: '1 0^k' repeated
+        // -- keeps a wrong start out of step for the whole chunk, and the corrections below advance one lane per round (40-50
+        // rounds measured on harmonic test signals; one or two with the realignment).  A walk that never realigned IS the
+        // exact walk; only those count in the end.
+        auto walk = [&](int e, bool act, int& x, int& cnt, bool lenient, bool& realigned) {
             bool go = act && e < GW_E;
-            if (act) { x = e < GW_E ? (int)GW_END : e; cnt = 0; }             // an END / LONG entry is passed on
+            if (act) { x = e < GW_E ? (int)GW_END : e; cnt = 0; realigned = false; }  // an END / LONG entry is passed on
             int r = e & (GW_E - 1);
             const int pos = cs + r;
             int wi = pos >> 5;
@@ -480,28 +486,50 @@ __device__ __forceinline__ bool decode_stream_2phase(const unsigned char* p, lon
             while (go) {
                 if (have < 32) { win |= (u64)words[wi < nwords + 2 ? wi : nwords + 1] << (32 - have); have += 32; ++wi; }
                 const int z = __builtin_clz((uint32_t)(win >> 32) | 1u);
-                const int used = 2 * z + k + 1, rn = r + used;
-                const bool end_ = r > rl1, lng = z >= zcap, lastc = rn >= rT, outc = rn >= chb;
+                const bool end_ = r > rl1;
+                const bool re = lenient && z >= 2 && !end_;                       // realign: skip the zeros, count nothing
+                const int used = re ? z : 2 * z + k + 1, rn = r + used;
+                const bool lng = !re && z >= zcap, lastc = rn >= rT, outc = rn >= chb;
                 int v = x;
                 v = outc ? rn - chb : v;
                 v = lastc ? (int)GW_END : v;
                 v = lng ? (int)GW_LONG : v;
                 v = end_ ? (int)GW_END : v;
                 x = v;
-                cnt += (end_ | lng) ? 0 : 1;
+                cnt += (end_ | lng | re) ? 0 : 1;
+                realigned |= re;
                 go = !(end_ | lng | lastc | outc);
                 win <<= (used & 63); have -= used; r = rn;            // (used <= 32 while `go` stays set)
             }
         };
         int my_entry = lane == 0 ? lead * 8 : 0, my_x = (int)GW_END, my_cnt = 0;
-        walk(my_entry, mine, my_x, my_cnt);                           // round 0: every chunk from its first bit -- a guess; prefix codes
-        for (int round = 0;; ++round) {                               // fall into step within a few codes, so most exits are right already
+        bool my_re = false;
+        // Round 0: every chunk from its first bit -- a guess; prefix codes fall into step within a few codes, so most exits are right
+        // already.  Then: lane i takes lane i - 1's exit as its entry and walks again if that differs from what it assumed.  Lane
+        // 0's entry is known (its walks are exact), so lane i is final once lane i - 1 is.
+        walk(my_entry, mine, my_x, my_cnt, lane > 0, my_re);
+        for (int round = 0;; ++round) {
             const int ex = (int)__shfl((unsigned long long)(unsigned)my_x, lane ? lane - 1 : 0, 64);
-            const bool redo = mine && lane > 0 && ex != my_entry;     // lane 0's entry is known; lane i is final once lane i - 1 is
+            const bool redo = mine && lane > 0 && ex != my_entry;
             if (!wave_any(redo)) break;
             if (round >= 16) return false;                            // (uniform) a stream that keeps its chunks out of step: slow kernel
             if (redo) my_entry = ex;
-            walk(my_entry, redo, my_x, my_cnt);
+            walk(my_entry, redo, my_x, my_cnt, true, my_re);
+        }
+        // Every lane now starts where its left neighbour ended.  A lane whose last walk realigned has not walked the code as it is
+        // written (a stream with longer zero prefixes than the reference coder makes, or a damaged one): those walk again, exactly,
+        // and the corrections repeat with exact walks.
+        if (wave_any(mine && my_re)) {
+            bool dummy = false;
+            walk(my_entry, mine && my_re, my_x, my_cnt, false, dummy);
+            for (int round = 0;; ++round) {
+                const int ex = (int)__shfl((unsigned long long)(unsigned)my_x, lane ? lane - 1 : 0, 64);
+                const bool redo = mine && lane > 0 && ex != my_entry;
+                if (!wave_any(redo)) break;
+                if (round >= 16) return false;
+                if (redo) my_entry = ex;
+                walk(my_entry, redo, my_x, my_cnt, false, dummy);
+            }
         }
         // ---- phase 2: output index of every chunk's first code ------------------------------------------------------
         if (wave_any(mine && my_x == (int)GW_LONG)) return false;     // (uniform) a code beyond 32 bits on the path
@@ -631,6 +659,22 @@ int frad_rows_compact(const void* rows, int64_t row_stride, const int64_t* row_b
     if (n_rows > 0 && out)
         hipLaunchKernelGGL(k_rows_gather, dim3((unsigned)n_rows), dim3(GT), 0, s, static_cast<const unsigned char*>(rows), (long long)row_stride,
                            reinterpret_cast<const long long*>(offsets), static_cast<unsigned char*>(out));
+    GOLCHK(hipGetLastError());
+    return FRAD_OK;
+}
+
+// diagnostic (not part of the ABI): the wave-per-frame kernel alone; todo[f] bit 0 / 1 = the threshold / coefficient stream of
+// frame f was left to the lane-per-frame kernel (tests pin which streams take the fast path)
+int frad_debug_golomb_decode_wave(const void* bodies, const int64_t* offsets, int64_t n_frames, int32_t N, int32_t C,
+                                  int32_t* q, int32_t* tq, int32_t* todo, void* stream) {
+    if (n_frames <= 0 || N < 1 || C < 1 || !bodies || !offsets || !q || !tq || !todo || n_frames > 0x7fffffffLL) return FRAD_E_INVALID;
+    long long wmax = ((long long)N * C * 16) / 32 + 64;
+    if (wmax > GW_WORDS) wmax = GW_WORDS;
+    const long long nq = (long long)N * C, nst = nq <= 512 ? nq : 27LL * C;
+    const int omax = (int)(nst + (nst >> 5) + 1);
+    hipLaunchKernelGGL(k_gol_decode_wave, dim3((unsigned)n_frames), dim3(64), gw_lds((int)wmax, omax), static_cast<hipStream_t>(stream),
+                       static_cast<const unsigned char*>(bodies), reinterpret_cast<const long long*>(offsets), nq, 27LL * C, q, tq,
+                       static_cast<int32_t*>(nullptr), todo, (int)wmax, omax);
     GOLCHK(hipGetLastError());
     return FRAD_OK;
 }

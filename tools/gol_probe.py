@@ -15,8 +15,13 @@ def timeit(fn, reps=10, warm=3):
 N, C = 2048, 2
 g = torch.Generator(device=dev).manual_seed(1)
 big = torch.empty(1 << 30, dtype=torch.uint8, device=dev); big2 = torch.empty_like(big)
-for F in (64, 1500, 15000):
+# two kinds of frames: noise-like (every bin busy) and tonal (a few hundred busy bins, the upper bands all zero: long runs of one
+# code, which is where a speculative decoder has to work for its synchronisation)
+for kind, F in (("noise", 64), ("noise", 1500), ("noise", 15000), ("tonal", 1500), ("tonal", 15000)):
     q = (torch.randn((F, N, C), generator=g, device=dev) * 6).round().to(torch.int32)
+    if kind == "tonal":
+        q = (torch.randn((F, N, C), generator=g, device=dev) * 40).round().to(torch.int32)
+        q[:, 300:, :] = 0
     tq = torch.randint(0, 30, (F, 27, C), generator=g, device=dev, dtype=torch.int32)
     flat, offs = core.p1_golomb_encode_batch(q, tq)
     def dec():
@@ -30,6 +35,6 @@ for F in (64, 1500, 15000):
     for _ in range(20): big2.copy_(big)
     a.record(); dec(); b.record(); torch.cuda.synchronize()
     dq, dt, st = dec()
-    print(json.dumps({"frames": F, "decode_ms": round(cold, 3), "decode_ms_after_20_copies": round(a.elapsed_time(b), 3),
+    print(json.dumps({"kind": kind, "frames": F, "decode_ms": round(cold, 3), "decode_ms_after_20_copies": round(a.elapsed_time(b), 3),
                       "encode_ms": round(timeit(lambda: core.p1_golomb_encode_batch(q, tq)), 3),
                       "bytes_per_frame": int(offs[-1].item()) // F, "ok": bool(torch.equal(dq, q) and torch.equal(dt, tq))}))
