@@ -420,10 +420,13 @@ __global__ void __launch_bounds__(64) k_gol_decode(const unsigned char* __restri
 // settle in 16 rounds are left to the lane-per-frame kernel (`todo`).
 constexpr int GW_WORDS = 6144;             // most stream words a wave holds in LDS (24 KiB); the launch sizes it for 16 bits per value
 constexpr int GW_E = 32;                   // longest code / entry range handled here
-constexpr int gw_lds(int wmax, int omax) { return (wmax + 2 + omax) * 4; }
+constexpr int GW_RING = 64;                // (entry maps) ring entries per lane (>= GW_E + the four positions of a batch)
+constexpr int GW_PITCH = 66;               // ring pitch in 16-bit entries (33 words: odd, lanes hit different banks)
+constexpr int gw_lds(int wmax, int omax, bool map = false) { return (wmax + 2 + omax) * 4 + (map ? 64 * GW_PITCH * 2 : 0); }
 constexpr uint32_t GW_END = 127, GW_LONG = 126;          // a walk's exit: offset 0 .. 31 into the next chunk, or one of these
 
 // one stream of the calling WAVE's frame; false = leave it to the slow kernel (nothing written)
+template <bool MAP>
 __device__ __forceinline__ bool decode_stream_2phase(const unsigned char* p, long long len, int32_t* __restrict__ out, long long cap, int wmax, int omax) {
     FRAD_DYN_SMEM(smem_);
     uint32_t* words = reinterpret_cast<uint32_t*>(smem_);
@@ -461,89 +464,176 @@ __device__ __forceinline__ bool decode_stream_2phase(const unsigned char* p, lon
         if (!((chb >> 5) & 1)) chb += 32;                         // an odd number of them: the lanes' window reads hit different banks
         const int nch = (T + chb - 1) / chb;
         const int cs = lane * chb;
-        // ---- phase 1: where does this lane's chunk begin?  (speculate, then correct) ---------------------------
-        // Chunk-relative positions r = pp - cs.  zcap = first zero run too long for a 32-bit code ("zcap or more").
-        const int zcap = (GW_E - k - 1) / 2 + 1;
-        const int rl1 = last1 - cs, rT = T - cs;                  // last '1' and stream end, relative to this chunk
-        const bool mine = lane < nch;
-        // walk the codes from chunk-relative position e to the first one that starts beyond the chunk: x = its offset there
-        // (< GW_E), GW_END (the stream ended: the last code may be cut short, or only zeros were left) or GW_LONG (a code this
-        // path does not take); cnt = codes that start in the chunk.  Selects, not branches: the lanes differ at every step.
-        // `lenient`: with the k of the reference coder (taken from the stream's maximum, p1tools.py:47-48) a code has at most ONE
-        // leading zero, so two or more zeros say "this is not a code boundary" and a lenient walk moves on to the next '1' (and
-        // notes that it did).  Without that, a run of equal values -- the zeros of a tonal frame's upper bands: '1 0^k' repeated
-        // -- keeps a wrong start out of step for the whole chunk, and the corrections below advance one lane per round (40-50
-        // rounds measured on harmonic test signals; one or two with the realignment).  A walk that never realigned IS the
-        // exact walk; only those count in the end.
-        auto walk = [&](int e, bool act, int& x, int& cnt, bool lenient, bool& realigned) {
-            bool go = act && e < GW_E;
-            if (act) { x = e < GW_E ? (int)GW_END : e; cnt = 0; realigned = false; }  // an END / LONG entry is passed on
-            int r = e & (GW_E - 1);
-            const int pos = cs + r;
-            int wi = pos >> 5;
-            u64 win = 0; int have = 0;
-            if (go) { win = (((u64)words[wi] << 32) | (u64)words[wi + 1]) << (pos & 31); have = 64 - (pos & 31); wi += 2; }
-            while (go) {
-                if (have < 32) { win |= (u64)words[wi < nwords + 2 ? wi : nwords + 1] << (32 - have); have += 32; ++wi; }
-                const int z = __builtin_clz((uint32_t)(win >> 32) | 1u);
-                const bool end_ = r > rl1;
-                const bool re = lenient && z >= 2 && !end_;                       // realign: skip the zeros, count nothing
-                const int used = re ? z : 2 * z + k + 1, rn = r + used;
-                const bool lng = !re && z >= zcap, lastc = rn >= rT, outc = rn >= chb;
-                int v = x;
-                v = outc ? rn - chb : v;
-                v = lastc ? (int)GW_END : v;
-                v = lng ? (int)GW_LONG : v;
-                v = end_ ? (int)GW_END : v;
-                x = v;
-                cnt += (end_ | lng | re) ? 0 : 1;
-                realigned |= re;
-                go = !(end_ | lng | lastc | outc);
-                win <<= (used & 63); have -= used; r = rn;            // (used <= 32 while `go` stays set)
+        int my_base = 0, my_cnt = 0, my_entry = 0;
+        if constexpr (MAP) {
+            // The exhaustive form (rounds 2 / 3 of this decoder; now behind the walks, for the streams they do not settle): the entry map of
+            // EVERY bit position of the chunk by a backward dynamic programme, entry(p) = entry(p + 2 z(p) + k + 1) + one code, in a
+            // ring of the last 64 positions (16-bit entries: exit offset or END / LONG in the low 7 bits, codes above); a code is at
+            // least k + 1 bits long, so for k >= 3 four positions are taken per LDS round trip.  Then 64 dependent look-ups chain the maps.
+            if (chb / (k + 1) > 511) return false;                // the 9-bit code count of an entry
+            unsigned short* rings = reinterpret_cast<unsigned short*>(obuf + omax);
+            unsigned short* ring = rings + lane * GW_PITCH;
+            // ---- phase 1: the entry map of this lane's chunk ---------------------------------------------------
+            const int ce = cs + chb;
+            if (lane < nch) {
+                // Everything in chunk-relative positions r = pp - cs.  zcap = first zero run too long for a 32-bit code ("zcap or more").
+                const int zcap = (GW_E - k - 1) / 2 + 1;
+                const int rl1 = last1 - cs, rT = T - cs;                      // last '1' and stream end, relative to this chunk
+                int z;
+                {
+                    const int wn = ce >> 5;                                   // (the last chunks may reach beyond the staged words: zeros)
+                    const uint32_t w0 = wn < nwords + 2 ? words[wn] : 0u, w1 = wn + 1 < nwords + 2 ? words[wn + 1] : 0u;
+                    z = w0 ? __builtin_clz(w0) : (w1 ? 32 + __builtin_clz(w1) : 64);
+                    if (z > zcap) z = zcap;
+                }
+                // entry of position r given the zero run z there: either final (`e`, ri < 0) or one more code behind ring slot `ri`.
+                // Branch-free (selects): the lanes of a wave sit in different cases at every position.
+                auto classify = [&](int r, int z_, uint32_t& e, int& ri) {
+                    const int rnx = r + 2 * z_ + k + 1;                               // where the next code starts
+                    const bool end_ = r > rl1, lng = z_ >= zcap, lastc = rnx >= rT, outc = rnx >= chb;
+                    uint32_t v = (uint32_t)(rnx - chb) | (1u << 7);                   // the code ends in the next chunk (exit offset < 32)
+                    v = lastc ? ((1u << 7) | GW_END) : v;                             // the stream's last code (maybe cut short)
+                    v = lng ? GW_LONG : v;
+                    v = end_ ? GW_END : v;                                            // zeros to the end: no code starts here
+                    e = v;
+                    const int slot = rnx & (GW_RING - 1);                             // (cs is a multiple of 32 and the ring index is taken mod 64 of r)
+                    ri = (end_ | lng | lastc | outc) ? (slot | (int)0x80000000) : slot;     // sign bit: the ring is not consulted
+                };
+                // one more code in front of entry t: the count sits above bit 7, so a LONG / END code in the low 7 bits rides along
+                auto finish = [&](uint32_t e, int ri, uint32_t t) -> uint32_t { return ri < 0 ? e : t + (1u << 7); };
+                for (int w = (ce >> 5) - 1; w >= (cs >> 5); --w) {
+                    const uint32_t cur = w < nwords + 2 ? words[w] : 0u;
+                    const int r0 = 32 * w + 31 - cs;                                  // relative position of the word's last bit
+                    if (k >= 3) {
+    #pragma unroll 2
+                        for (int i = 0; i < 32; i += 4) {                 // positions r0 - i ... - 3: mutually independent (k + 1 >= 4)
+                            uint32_t e[4]; int ri[4]; uint32_t t[4];
+    #pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const bool one = (cur >> (i + j)) & 1u;
+                                z = one ? 0 : (z < zcap ? z + 1 : zcap);
+                                classify(r0 - i - j, z, e[j], ri[j]);
+                            }
+    #pragma unroll
+                            for (int j = 0; j < 4; ++j) t[j] = ring[ri[j] & (GW_RING - 1)];
+    #pragma unroll
+                            for (int j = 0; j < 4; ++j) ring[(r0 - i - j) & (GW_RING - 1)] = (unsigned short)finish(e[j], ri[j], t[j]);
+                        }
+                    } else {
+                        for (int i = 0; i < 32; ++i) {
+                            const bool one = (cur >> i) & 1u;
+                            z = one ? 0 : (z < zcap ? z + 1 : zcap);
+                            uint32_t e; int ri;
+                            classify(r0 - i, z, e, ri);
+                            const uint32_t t = ring[ri & (GW_RING - 1)];
+                            ring[(r0 - i) & (GW_RING - 1)] = (unsigned short)finish(e, ri, t);
+                        }
+                    }
+                }
             }
-        };
-        int my_entry = lane == 0 ? lead * 8 : 0, my_x = (int)GW_END, my_cnt = 0;
-        bool my_re = false;
-        // Round 0: every chunk from its first bit -- a guess; prefix codes fall into step within a few codes, so most exits are right
-        // already.  Then: lane i takes lane i - 1's exit as its entry and walks again if that differs from what it assumed.  Lane
-        // 0's entry is known (its walks are exact), so lane i is final once lane i - 1 is.
-        walk(my_entry, mine, my_x, my_cnt, lane > 0, my_re);
-        for (int round = 0;; ++round) {
-            const int ex = (int)__shfl((unsigned long long)(unsigned)my_x, lane ? lane - 1 : 0, 64);
-            const bool redo = mine && lane > 0 && ex != my_entry;
-            if (!wave_any(redo)) break;
-            if (round >= 16) return false;                            // (uniform) a stream that keeps its chunks out of step: slow kernel
-            if (redo) my_entry = ex;
-            walk(my_entry, redo, my_x, my_cnt, true, my_re);
-        }
-        // Every lane now starts where its left neighbour ended.  A lane whose last walk realigned has not walked the code as it is
-        // written (a stream with longer zero prefixes than the reference coder makes, or a damaged one): those walk again, exactly,
-        // and the corrections repeat with exact walks.
-        if (wave_any(mine && my_re)) {
-            bool dummy = false;
-            walk(my_entry, mine && my_re, my_x, my_cnt, false, dummy);
+            FRAD_LDS_BARRIER();
+            // ---- phase 2: chain the maps (every lane walks the same chain and keeps its own link) -----------------
+            {
+                int e = lead * 8, base = 0; bool ended = false, bad = false;
+                for (int i = 0; i < nch; ++i) {
+                    if (!ended) {
+                        const uint32_t t = rings[i * GW_PITCH + e];
+                        const uint32_t x = t & 127u;
+                        if (x == GW_LONG) { bad = true; break; }
+                        if (i == lane) { my_base = base; my_entry = e; my_cnt = (int)(t >> 7); }
+                        base += (int)(t >> 7);
+                        if (x == GW_END) ended = true; else e = (int)x;
+                    }
+                }
+                if (bad) return false;                                                // (uniform: every lane read the same entries)
+                total = base < cap ? base : cap;
+            }
+        } else {
+            // ---- phase 1: where does this lane's chunk begin?  (speculate, then correct) ---------------------------
+            // Chunk-relative positions r = pp - cs.  zcap = first zero run too long for a 32-bit code ("zcap or more").
+            const int zcap = (GW_E - k - 1) / 2 + 1;
+            const int rl1 = last1 - cs, rT = T - cs;                  // last '1' and stream end, relative to this chunk
+            const bool mine = lane < nch;
+            // walk the codes from chunk-relative position e to the first one that starts beyond the chunk: x = its offset there
+            // (< GW_E), GW_END (the stream ended: the last code may be cut short, or only zeros were left) or GW_LONG (a code this
+            // path does not take); cnt = codes that start in the chunk.  Selects, not branches: the lanes differ at every step.
+            // `lenient`: with the k of the reference coder (taken from the stream's maximum, p1tools.py:47-48) a code has at most ONE
+            // leading zero, so two or more zeros say "this is not a code boundary" and a lenient walk moves on to the next '1' (and
+            // notes that it did).  Without that, a run of equal values -- the zeros of a tonal frame's upper bands: '1 0^k' repeated
+            // -- keeps a wrong start out of step for the whole chunk, and the corrections below advance one lane per round (40-50
+            // rounds measured on harmonic test signals; one or two with the realignment).  A walk that never realigned IS the
+            // exact walk; only those count in the end.
+            auto walk = [&](int e, bool act, int& x, int& cnt, bool lenient, bool& realigned) {
+                bool go = act && e < GW_E;
+                if (act) { x = e < GW_E ? (int)GW_END : e; cnt = 0; realigned = false; }  // an END / LONG entry is passed on
+                int r = e & (GW_E - 1);
+                const int pos = cs + r;
+                int wi = pos >> 5;
+                u64 win = 0; int have = 0;
+                if (go) { win = (((u64)words[wi] << 32) | (u64)words[wi + 1]) << (pos & 31); have = 64 - (pos & 31); wi += 2; }
+                while (go) {
+                    if (have < 32) { win |= (u64)words[wi < nwords + 2 ? wi : nwords + 1] << (32 - have); have += 32; ++wi; }
+                    const int z = __builtin_clz((uint32_t)(win >> 32) | 1u);
+                    const bool end_ = r > rl1;
+                    const bool re = lenient && z >= 2 && !end_;                       // realign: skip the zeros, count nothing
+                    const int used = re ? z : 2 * z + k + 1, rn = r + used;
+                    const bool lng = !re && z >= zcap, lastc = rn >= rT, outc = rn >= chb;
+                    int v = x;
+                    v = outc ? rn - chb : v;
+                    v = lastc ? (int)GW_END : v;
+                    v = lng ? (int)GW_LONG : v;
+                    v = end_ ? (int)GW_END : v;
+                    x = v;
+                    cnt += (end_ | lng | re) ? 0 : 1;
+                    realigned |= re;
+                    go = !(end_ | lng | lastc | outc);
+                    win <<= (used & 63); have -= used; r = rn;            // (used <= 32 while `go` stays set)
+                }
+            };
+            my_entry = lane == 0 ? lead * 8 : 0; my_cnt = 0;
+            int my_x = (int)GW_END;
+            bool my_re = false;
+            // Round 0: every chunk from its first bit -- a guess; prefix codes fall into step within a few codes, so most exits are right
+            // already.  Then: lane i takes lane i - 1's exit as its entry and walks again if that differs from what it assumed.  Lane
+            // 0's entry is known (its walks are exact), so lane i is final once lane i - 1 is.
+            walk(my_entry, mine, my_x, my_cnt, lane > 0, my_re);
             for (int round = 0;; ++round) {
                 const int ex = (int)__shfl((unsigned long long)(unsigned)my_x, lane ? lane - 1 : 0, 64);
                 const bool redo = mine && lane > 0 && ex != my_entry;
                 if (!wave_any(redo)) break;
-                if (round >= 16) return false;
+                if (round >= 16) return false;                            // (uniform) a stream that keeps its chunks out of step: slow kernel
                 if (redo) my_entry = ex;
-                walk(my_entry, redo, my_x, my_cnt, false, dummy);
+                walk(my_entry, redo, my_x, my_cnt, true, my_re);
             }
+            // Every lane now starts where its left neighbour ended.  A lane whose last walk realigned has not walked the code as it is
+            // written (a stream with longer zero prefixes than the reference coder makes, or a damaged one): those walk again, exactly,
+            // and the corrections repeat with exact walks.
+            if (wave_any(mine && my_re)) {
+                bool dummy = false;
+                walk(my_entry, mine && my_re, my_x, my_cnt, false, dummy);
+                for (int round = 0;; ++round) {
+                    const int ex = (int)__shfl((unsigned long long)(unsigned)my_x, lane ? lane - 1 : 0, 64);
+                    const bool redo = mine && lane > 0 && ex != my_entry;
+                    if (!wave_any(redo)) break;
+                    if (round >= 16) return false;
+                    if (redo) my_entry = ex;
+                    walk(my_entry, redo, my_x, my_cnt, false, dummy);
+                }
+            }
+            // ---- phase 2: output index of every chunk's first code ------------------------------------------------------
+            if (wave_any(mine && my_x == (int)GW_LONG)) return false;     // (uniform) a code beyond 32 bits on the path
+            if (!mine) my_cnt = 0;
+            my_base = my_cnt;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = (int)__shfl((unsigned long long)(unsigned)my_base, lane >= off ? lane - off : lane, 64);
+                my_base += lane >= off ? o : 0;
+            }
+            {
+                const int sum = (int)__shfl((unsigned long long)(unsigned)my_base, 63, 64);
+                total = sum < cap ? sum : cap;
+            }
+            my_base -= my_cnt;
         }
-        // ---- phase 2: output index of every chunk's first code ------------------------------------------------------
-        if (wave_any(mine && my_x == (int)GW_LONG)) return false;     // (uniform) a code beyond 32 bits on the path
-        if (!mine) my_cnt = 0;
-        int my_base = my_cnt;
-        for (int off = 1; off < 64; off <<= 1) {
-            const int o = (int)__shfl((unsigned long long)(unsigned)my_base, lane >= off ? lane - off : lane, 64);
-            my_base += lane >= off ? o : 0;
-        }
-        {
-            const int sum = (int)__shfl((unsigned long long)(unsigned)my_base, 63, 64);
-            total = sum < cap ? sum : cap;
-        }
-        my_base -= my_cnt;
         // ---- phase 3: every lane decodes the codes that start in its chunk ------------------------------------
         // The values go to LDS first when the frame fits (value i at word i + i / 32: the lanes' output ranges begin about 64
         // values apart), and leave as whole 256-byte / 1 KiB rows -- 64 lanes storing 4 bytes each at 64 places were the
@@ -601,20 +691,25 @@ __device__ __forceinline__ bool decode_stream_2phase(const unsigned char* p, lon
     return true;
 }
 
+// MAP = false: every frame, the walks.  MAP = true: the frames (streams) the walks left in `todo`, with the entry maps; what
+// neither takes stays in `todo` for the lane-per-frame kernel.
+template <bool MAP>
 __global__ void __launch_bounds__(64) k_gol_decode_wave(const unsigned char* __restrict__ bodies, const long long* __restrict__ offsets,
                                                         long long nq, long long ntq, int32_t* __restrict__ q, int32_t* __restrict__ tq,
                                                         int32_t* __restrict__ status, int32_t* __restrict__ todo, int wmax, int omax) {
     const long long f = blockIdx.x;
+    int mine = 3;
+    if constexpr (MAP) { mine = todo[f]; if (mine == 0) return; }                  // (uniform: one wave, one frame)
     const unsigned char* b = bodies + offsets[f];
     long long len = offsets[f + 1] - offsets[f];
     long long tlen = 0;
-    if (threadIdx.x == 0 && status) status[f] = len < 4 ? 1 : 0;
+    if (!MAP && threadIdx.x == 0 && status) status[f] = len < 4 ? 1 : 0;
     if (len >= 4) {
         tlen = ((long long)b[0] << 24) | ((long long)b[1] << 16) | ((long long)b[2] << 8) | (long long)b[3];
         if (tlen > len - 4) tlen = len - 4;
     } else len = 4;
-    const bool ok_t = decode_stream_2phase(b + 4, tlen, tq + f * ntq, ntq, wmax, omax);
-    const bool ok_q = decode_stream_2phase(b + 4 + tlen, len - 4 - tlen, q + f * nq, nq, wmax, omax);
+    const bool ok_t = (mine & 1) ? decode_stream_2phase<MAP>(b + 4, tlen, tq + f * ntq, ntq, wmax, omax) : true;
+    const bool ok_q = (mine & 2) ? decode_stream_2phase<MAP>(b + 4 + tlen, len - 4 - tlen, q + f * nq, nq, wmax, omax) : true;
     if (threadIdx.x == 0) todo[f] = (ok_t ? 0 : 1) | (ok_q ? 0 : 2);
 }
 
@@ -666,15 +761,19 @@ int frad_rows_compact(const void* rows, int64_t row_stride, const int64_t* row_b
 // diagnostic (not part of the ABI): the wave-per-frame kernel alone; todo[f] bit 0 / 1 = the threshold / coefficient stream of
 // frame f was left to the lane-per-frame kernel (tests pin which streams take the fast path)
 int frad_debug_golomb_decode_wave(const void* bodies, const int64_t* offsets, int64_t n_frames, int32_t N, int32_t C,
-                                  int32_t* q, int32_t* tq, int32_t* todo, void* stream) {
+                                  int32_t* q, int32_t* tq, int32_t* todo, int32_t with_maps, void* stream) {
     if (n_frames <= 0 || N < 1 || C < 1 || !bodies || !offsets || !q || !tq || !todo || n_frames > 0x7fffffffLL) return FRAD_E_INVALID;
     long long wmax = ((long long)N * C * 16) / 32 + 64;
     if (wmax > GW_WORDS) wmax = GW_WORDS;
     const long long nq = (long long)N * C, nst = nq <= 512 ? nq : 27LL * C;
     const int omax = (int)(nst + (nst >> 5) + 1);
-    hipLaunchKernelGGL(k_gol_decode_wave, dim3((unsigned)n_frames), dim3(64), gw_lds((int)wmax, omax), static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(k_gol_decode_wave<false>, dim3((unsigned)n_frames), dim3(64), gw_lds((int)wmax, omax), static_cast<hipStream_t>(stream),
                        static_cast<const unsigned char*>(bodies), reinterpret_cast<const long long*>(offsets), nq, 27LL * C, q, tq,
                        static_cast<int32_t*>(nullptr), todo, (int)wmax, omax);
+    if (with_maps)
+        hipLaunchKernelGGL(k_gol_decode_wave<true>, dim3((unsigned)n_frames), dim3(64), gw_lds((int)wmax, omax, true), static_cast<hipStream_t>(stream),
+                           static_cast<const unsigned char*>(bodies), reinterpret_cast<const long long*>(offsets), nq, 27LL * C, q, tq,
+                           static_cast<int32_t*>(nullptr), todo, (int)wmax, omax);
     GOLCHK(hipGetLastError());
     return FRAD_OK;
 }
@@ -701,7 +800,10 @@ int frad_p1_golomb_decode(const void* bodies, const int64_t* offsets, int64_t n_
         // 4096 was measured: 25 KiB per wave leaves six waves on a CU -- 0.46 ms per 15 000 frames against 0.37 without
         const long long nq = (long long)N * C, nst = nq <= 512 ? nq : 27LL * C;
         const int omax = (int)(nst + (nst >> 5) + 1);
-        hipLaunchKernelGGL(k_gol_decode_wave, dim3((unsigned)n_frames), dim3(64), gw_lds((int)wmax, omax), s, static_cast<const unsigned char*>(bodies),
+        hipLaunchKernelGGL(k_gol_decode_wave<false>, dim3((unsigned)n_frames), dim3(64), gw_lds((int)wmax, omax), s, static_cast<const unsigned char*>(bodies),
+                           reinterpret_cast<const long long*>(offsets), (long long)N * C, 27LL * C, q, tq, status, todo, (int)wmax, omax);
+        // behind it, for the streams the walks did not settle (a wave whose frame has none returns at once): the entry maps
+        hipLaunchKernelGGL(k_gol_decode_wave<true>, dim3((unsigned)n_frames), dim3(64), gw_lds((int)wmax, omax, true), s, static_cast<const unsigned char*>(bodies),
                            reinterpret_cast<const long long*>(offsets), (long long)N * C, 27LL * C, q, tq, status, todo, (int)wmax, omax);
     }
     hipLaunchKernelGGL(k_gol_decode, dim3((unsigned)blocks), dim3(64), DEC_LDS, s, static_cast<const unsigned char*>(bodies),

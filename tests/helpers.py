@@ -158,6 +158,18 @@ class EmuBackend:
         self.lib.p1_golomb_decode(buf.ctypes.data, offs.ctypes.data, F, N, C, q.ctypes.data, tq.ctypes.data, st.ctypes.data)
         return q[:F], tq[:F], st[:F]
 
+    def golomb_decode_fast_only(self, bodies, N, C, with_maps):
+        """the wave-per-frame kernels alone (frad_debug_golomb_decode_wave): -> q, tq, todo (bit 0 / 1: stream left to the slow kernel)"""
+        import ctypes as ct
+        F = len(bodies)
+        offs = np.zeros(F + 1, np.int64); np.cumsum([len(b) for b in bodies], out=offs[1:])
+        buf = np.frombuffer(b"".join(bodies) + b"\0" * 8, np.uint8).copy()
+        q = np.zeros((F, N, C), np.int32); tq = np.zeros((F, 27, C), np.int32); todo = np.full(F, -1, np.int32)
+        rc = self.lib.dll.frad_debug_golomb_decode_wave(ct.c_void_p(buf.ctypes.data), ct.c_void_p(offs.ctypes.data), ct.c_int64(F), ct.c_int32(N), ct.c_int32(C),
+                                                        ct.c_void_p(q.ctypes.data), ct.c_void_p(tq.ctypes.data), ct.c_void_p(todo.ctypes.data), ct.c_int32(with_maps), ct.c_void_p(0))
+        assert rc == 0
+        return q, tq, todo
+
     def p1_ola(self, frames, ratio, prev_tail=None):
         F, N, C = frames.shape
         cut = N * (ratio - 1) // ratio
@@ -315,6 +327,23 @@ class GpuBackend:
         q, tq, st = core.p1_golomb_decode_batch(flat, t.from_numpy(offs).to(self.dev), N, C)
         t.cuda.synchronize()
         return q.cpu().numpy(), tq.cpu().numpy(), st.cpu().numpy()
+
+    def golomb_decode_fast_only(self, bodies, N, C, with_maps):
+        import ctypes as ct
+        from frad_python_amd import _lib
+        t = self.torch
+        F = len(bodies)
+        offs = np.zeros(F + 1, np.int64); np.cumsum([len(b) for b in bodies], out=offs[1:])
+        flat = t.from_numpy(np.frombuffer(b"".join(bodies) + b"\0" * 8, np.uint8).copy()).to(self.dev)
+        od = t.from_numpy(offs).to(self.dev)
+        q = t.zeros((F, N, C), dtype=t.int32, device=self.dev); tq = t.zeros((F, 27, C), dtype=t.int32, device=self.dev)
+        todo = t.full((F,), -1, dtype=t.int32, device=self.dev)
+        rc = _lib.load().dll.frad_debug_golomb_decode_wave(ct.c_void_p(flat.data_ptr()), ct.c_void_p(od.data_ptr()), ct.c_int64(F), ct.c_int32(N), ct.c_int32(C),
+                                                           ct.c_void_p(q.data_ptr()), ct.c_void_p(tq.data_ptr()), ct.c_void_p(todo.data_ptr()), ct.c_int32(with_maps),
+                                                           ct.c_void_p(int(t.cuda.current_stream().cuda_stream)))
+        assert rc == 0
+        t.cuda.synchronize()
+        return q.cpu().numpy(), tq.cpu().numpy(), todo.cpu().numpy()
 
     def p1_ola(self, frames, ratio, prev_tail=None):
         from frad_python_amd import core

@@ -308,6 +308,30 @@ def test_golomb_streams_that_do_not_fall_into_step(be):
         assert np.array_equal(dt[i], tq[0]), i
 
 
+def test_golomb_fast_kernels_take_what_a_coder_writes(be):
+    """Which decoder runs matters: the lane-per-frame kernel costs milliseconds per batch.  The walks (first wave kernel) must settle
+    noise-like frames AND tonal ones (the upper bands all zero: a run of one code, where a wrongly started walk never falls into
+    step by itself) AND the reference's own frames; very quiet frames (k = 1: '10' repeated reads as a valid code from the wrong
+    bit too) may be left to the entry-map kernel behind them, which must take everything a coder can write."""
+    rng = np.random.default_rng(2024)
+    N, C = 2048, 2
+    F = 3 if be.name == "emu" else 24
+    noise = np.rint(rng.normal(0, 6, (F, N, C))).astype(np.int32)
+    tonal = np.rint(rng.normal(0, 40, (F, N, C))).astype(np.int32); tonal[:, 300:, :] = 0
+    gaps = np.rint(rng.normal(0, 9, (F, N, C))).astype(np.int32); gaps[:, 100:900, :] = 0; gaps[:, 1200:, :] = 0
+    quiet = (rng.integers(-2, 3, (F, N, C)) * (rng.random((F, N, C)) < 0.2)).astype(np.int32); quiet[:, 0, 0] = 2
+    tq = rng.integers(0, 30, (F, 27, C)).astype(np.int32)
+    for name, q, walks_only in (("noise", noise, True), ("tonal", tonal, True), ("gaps", gaps, True), ("quiet", quiet, False)):
+        bodies = be.golomb_encode(q, tq)
+        if walks_only:
+            dq, dt, todo = be.golomb_decode_fast_only(bodies, N, C, 0)
+            assert not todo.any(), (name, todo)
+            assert np.array_equal(dq, q) and np.array_equal(dt, tq), name
+        dq, dt, todo = be.golomb_decode_fast_only(bodies, N, C, 1)
+        assert not todo.any(), (name, "with maps", todo)
+        assert np.array_equal(dq, q) and np.array_equal(dt, tq), name
+
+
 def test_golomb_decoder_on_damaged_streams(be):
     """Random bit flips and zero runs inside valid bodies: long codes (> 64 bits), spurious early ends, values beyond
     int32 -- the wave-per-frame decoder must hand what it cannot take to the lane-per-frame one, and both must agree with

@@ -16,7 +16,7 @@ for kind, F in (("noise", 1500), ("tonal", 1500)):
     flat, offs = core.p1_golomb_encode_batch(q, tq)
     qo = torch.zeros_like(q); to = torch.zeros_like(tq); todo = torch.full((F,), -1, dtype=torch.int32, device=dev)
     rc = dll.frad_debug_golomb_decode_wave(ctypes.c_void_p(flat.data_ptr()), ctypes.c_void_p(offs.data_ptr()), ctypes.c_int64(F), ctypes.c_int32(N), ctypes.c_int32(C),
-                                           ctypes.c_void_p(qo.data_ptr()), ctypes.c_void_p(to.data_ptr()), ctypes.c_void_p(todo.data_ptr()),
+                                           ctypes.c_void_p(qo.data_ptr()), ctypes.c_void_p(to.data_ptr()), ctypes.c_void_p(todo.data_ptr()), ctypes.c_int32(0),
                                            ctypes.c_void_p(int(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     t = todo.cpu().numpy()
