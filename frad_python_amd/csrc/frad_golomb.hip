@@ -408,16 +408,18 @@ __global__ void __launch_bounds__(64) k_gol_decode(const unsigned char* __restri
 }
 
 // ---- decode, one WAVE per frame (the fast path) ----------------------------------------------------------------------
-// The stream sits in LDS as big-endian words; lane i owns the bits [i CHB, (i+1) CHB), CHB a multiple of 32.  A prefix code's
-// boundaries are a sequential dependency -- but a decoder started at a wrong bit falls into step with the true sequence after
-// a few codes (Exp-Golomb codes synchronise quickly), so: phase 1, all lanes at once, walks the code lengths of the chunk from
-// its first bit and notes where the walk leaves the chunk; every lane then takes its left neighbour's exit as its entry and
-// walks again if that differs from what it assumed, until no lane changes (lane 0's entry is known, so lane i is right after
-// at most i rounds; in practice two walks).  Round 2 of VERDICT r2's list replaced the exhaustive entry map of every bit
-// position (a backward dynamic programme, 21 instructions x 392 positions per lane) by these walks (~20 x 64 codes, twice).
-// Phase 2: a wave scan of the chunks' code counts.  Phase 3, all lanes at once: each decodes exactly its own codes from a
-// 64-bit window over the LDS words.  Codes longer than 32 bits, k > 30, streams beyond the LDS budget and streams that do not
-// settle in 16 rounds are left to the lane-per-frame kernel (`todo`).
+// The stream sits in LDS as big-endian words; lane i owns the bits [i CHB, (i+1) CHB), CHB an odd number of words.  A prefix
+// code's boundaries are a sequential dependency.  Two ways around it, two instantiations of one kernel:
+//   MAP = false (every frame): SPECULATE -- all lanes at once walk the code lengths of their chunk from a guessed entry (its
+//     first bit) and note where the walk leaves the chunk; every lane then takes its left neighbour's exit as its entry and
+//     walks again if that differs from what it assumed, until no lane changes (lane 0's entry is known, so lane i is right
+//     after at most i rounds).  The walks are lenient (see `walk`), which is what makes tonal frames settle in a round or
+//     two; whatever realigned is walked again exactly.  ~20 instructions per code and walk.
+//   MAP = true (the streams the walks did not settle in 16 rounds, `todo`): the entry map of EVERY bit position of the chunk
+//     by a backward dynamic programme (21 instructions x 392 positions per lane whatever the data), then 64 chained look-ups.
+// Phase 2: output index of each chunk's first code.  Phase 3, all lanes at once: each decodes exactly its own codes from a
+// 64-bit window over the LDS words.  Codes longer than 32 bits, k > 30 and streams beyond the LDS budget are left to the
+// lane-per-frame kernel (`todo`).
 constexpr int GW_WORDS = 6144;             // most stream words a wave holds in LDS (24 KiB); the launch sizes it for 16 bits per value
 constexpr int GW_E = 32;                   // longest code / entry range handled here
 constexpr int GW_RING = 64;                // (entry maps) ring entries per lane (>= GW_E + the four positions of a batch)
