@@ -35,6 +35,19 @@ for secs in (60, 600):
                       "K7_ms": round(t7, 4), "K7_frac": round(b7 / t7 / 1e6 / 8000, 4),
                       "K8_ms": round(t8, 4), "K8_frac": round(b8 / t8 / 1e6 / 8000, 4)}))
     if secs == 600:
+        # the same on a tonal signal (eight partials + a little noise): few busy bins with large codes, the upper bands quantised to
+        # zero -- K7's exact fall-backs and K8's table misses depend on the data, the line above is noise
+        tt = torch.arange(n, device=dev, dtype=torch.float64)
+        sig = sum(a * torch.sin(2 * np.pi * f0 / 48000 * tt + ph) for a, f0, ph in
+                  ((9000, 220.0, 0.1), (5000, 440.0, 1.0), (4000, 660.0, 2.0), (2500, 880.0, 0.5), (2000, 1320.0, 0.3), (1200, 2640.0, 1.7), (800, 5280.0, 2.9), (300, 9000.0, 0.7)))
+        tone = (sig[:, None] * torch.tensor([1.0, 0.8], device=dev, dtype=torch.float64) + torch.randn((n, C), generator=g, device=dev) * 20).clamp(-32768, 32767).to(torch.int16)
+        q2, tq2 = core.p1_analogue_batch(tone, "s16le", F, N, C, 16, 48000, loss, frame_stride=hop)
+        t7t = timeit(lambda: core.p1_analogue_batch(tone, "s16le", F, N, C, 16, 48000, loss, frame_stride=hop))
+        t8t = timeit(lambda: core.p1_digital_batch(q2, tq2, N, C, 16, 48000))
+        print(json.dumps({"secs": secs, "frames": F, "signal": "tonal", "K7_ms": round(t7t, 4), "K7_frac": round(b7 / t7t / 1e6 / 8000, 4),
+                          "K8_ms": round(t8t, 4), "K8_frac": round(b8 / t8t / 1e6 / 8000, 4), "q_absmax": int(q2.abs().max().item()),
+                          "q_zero_frac": round(float((q2 == 0).float().mean().item()), 3)}))
+        del tt, sig, tone, q2, tq2
         out = torch.empty((F, N * C * 8), dtype=torch.uint8, device=dev)
         am = torch.empty(F, dtype=torch.float64, device=dev)
         ta = timeit(lambda: core.analogue_batch(0, pcm, "s16le", F, N, C, 64, True, frame_stride=hop, check_overflow=False, out=out, absmax=am))
