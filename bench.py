@@ -58,9 +58,28 @@ def launch_ranks(n: int, argv: list[str]) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    # wait for all of them -- but a rank that dies (no such device, out of memory) must not leave the others waiting at the
+    # rendezvous for ever: the first non-zero exit ends the job
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            rc = max(rc, abs(code))
+        if rc and live:
+            for p in live:
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()                                  # (this child's own PID)
+            print(f"bench.py: a rank exited with {rc}; the others were stopped", file=sys.stderr)
+            break
     return rc
 
 
@@ -143,6 +162,8 @@ def main():
 
     if args.dry_run:
         # rendezvous + timing protocol only: gloo on CPU, no device, no kernels (tests/test_parallel.py)
+        if os.environ.get("FRAD_BENCH_DRYRUN_DIE") == str(rank):              # (test hook: this rank is lost before the rendezvous)
+            sys.exit(3)
         dist = None
         if world > 1:
             import torch.distributed as dist
@@ -166,6 +187,9 @@ def main():
     # devices round-robin) -- the data path has no collective either way
     backend = os.environ.get("FRAD_BENCH_BACKEND", "nccl")
     local = local % torch.cuda.device_count() if backend != "nccl" else local
+    if local >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} wants GPU {local}, this node shows {torch.cuda.device_count()} "
+                 "(FRAD_BENCH_BACKEND=gloo lets ranks share devices for a rehearsal)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None

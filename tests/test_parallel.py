@@ -79,3 +79,20 @@ def test_bench_launcher_starts_one_process_per_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["clips_rank0"] == 2048
     assert d["ms_per_step"] >= 20.0                          # MAX over ranks: rank 1 sleeps 20 ms
+
+
+def test_bench_launcher_ends_the_job_when_a_rank_is_lost():
+    """A rank that dies before the rendezvous (no such GPU, out of memory) must not leave the others waiting for ever: the launcher
+    stops them and returns the failure (seen on a one-GPU box: `bench.py --gpus 2` sat silent until the box's watchdog)."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["FRAD_BENCH_DRYRUN_DIE"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1000:])
+    assert time.time() - t0 < 100
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
