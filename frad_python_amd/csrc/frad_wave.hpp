@@ -534,7 +534,10 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
     }
     // ---- pair step, once: X[s][0..3] = X[k], X[M - k], X[M + k], X[N - k], k = wave_job_k(l, s); lane 0 of slot 0 (k = 0)
     //      carries X[0], X[512], X[M], X[1536] (the self-paired bins take the places of the two bins it does not have)
-    T X[16][4];
+    // Registers hold ONE half of the coefficients at a time while the band energies are taken (XH = classes 2, 3: the bins from M
+    // up; XL = classes 0, 1), the wave's planes the other: all 128 registers' worth live through the pair step and pass A had 25
+    // doubles per lane spilled to scratch -- 12.8 KB per frame that did reach HBM (578 MB measured for 372 MB algorithmic).
+    T XH[16][2], XL[16][2];
     // plane address of local bin b (0 .. 1023): row b >> 5 (pitch 34 doubles), column b & 31
     auto paddr = [&](int b) -> int { return ((b >> 5) * 34 + (b & 31)) * 8; };
     unsigned char* plw = wbuf + h * kK7PlaneBytes;
@@ -556,13 +559,14 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
             const cx<T> p = cmul(zk + zp, ptab[s & 1][0]), qq = cmul(zk - zp, ptab[s & 1][1]);
             const cx<T> S = p + qq, D = p - qq;
             const T xm = (D.x - D.y) * K<T>::s2, xp = (D.x + D.y) * K<T>::s2;
-            if (s == 0) { X[0][0] = S.x; X[0][1] = lane0 ? xs0 : xm; X[0][2] = lane0 ? xm : xp; X[0][3] = lane0 ? xs1 : -S.y; }
-            else { X[s][0] = S.x; X[s][1] = xm; X[s][2] = xp; X[s][3] = -S.y; }
-            // round 0 of pass A: bins below M go to the plane as they appear
+            T x0, x1;
+            if (s == 0) { x0 = S.x; x1 = lane0 ? xs0 : xm; XH[0][0] = lane0 ? xm : xp; XH[0][1] = lane0 ? xs1 : -S.y; }
+            else { x0 = S.x; x1 = xm; XH[s][0] = xp; XH[s][1] = -S.y; }
+            // round 0 of pass A: bins below M go to the plane as they appear (and stay only there until round 1)
             const int k = wave_job_k(l, s);
             const int kb1 = (s == 0 && lane0) ? 512 : M - k;
-            *reinterpret_cast<T*>(plw + paddr(k)) = X[s][0];
-            *reinterpret_cast<T*>(plw + paddr(kb1)) = X[s][1];
+            *reinterpret_cast<T*>(plw + paddr(k)) = x0;
+            *reinterpret_cast<T*>(plw + paddr(kb1)) = x1;
             FRAD_FENCE();
         }
     }
@@ -611,14 +615,24 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
     run_sums(ic<0>{});
     team_sync<64>();                                              // round 0 read: the planes take the upper half of the bins
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
+    for (int s = 0; s < 16; ++s) {                                // the halves change places: a lane reads back exactly what it wrote
         const int k = wave_job_k(l, s);
         const int kb3 = (s == 0 && lane0) ? 512 : M - k;          // local bin of N - k (lane 0, slot 0: 1536)
-        *reinterpret_cast<T*>(plw + paddr(k)) = X[s][2];
-        *reinterpret_cast<T*>(plw + paddr(kb3)) = X[s][3];
+        T* pa = reinterpret_cast<T*>(plw + paddr(k));
+        T* pb = reinterpret_cast<T*>(plw + paddr(kb3));
+        XL[s][0] = *pa; XL[s][1] = *pb;
+        *pa = XH[s][0]; *pb = XH[s][1];
     }
     team_sync<64>();
     run_sums(ic<1>{});
+    team_sync<64>();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {                                // the upper half back into registers: the buffer is about to be reused
+        const int k = wave_job_k(l, s);
+        const int kb3 = (s == 0 && lane0) ? 512 : M - k;
+        XH[s][0] = *reinterpret_cast<const T*>(plw + paddr(k));
+        XH[s][1] = *reinterpret_cast<const T*>(plw + paddr(kb3));
+    }
 #ifndef FRAD_HOST_EMULATION
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // every plane read has returned: the DMA may land in [8 KiB, 16 KiB)
 #endif
@@ -704,7 +718,7 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
 #pragma unroll
                 for (int cq = 0; cq < 4; ++cq) {                  // np.linspace without its end point: t0 + i * step (two roundings)
                     const double y = (double)(int)(en[cq] & 1023u) * rc[cq][1];
-                    qv[cq] = k7_quantise<EXACT>(X[s][cq], y + rc[cq][0], scale_f, pw.scale, undecided);
+                    qv[cq] = k7_quantise<EXACT>(cq < 2 ? XL[s][cq] : XH[s][cq - 2], y + rc[cq][0], scale_f, pw.scale, undecided);
                 }
                 const int tt = s < 8 ? s : 15 - s, tl = tt - gi * (JPG / 2);
                 const int offa = 64 * tl * ES + (s < 8 ? la : lb);
@@ -732,8 +746,8 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
                 const v2u e2 = pk2[0];
                 const uint32_t e1 = e2[0] >> 16, e3 = e2[1] >> 16;
                 const v2d r1 = recv[e1 >> 10], r3 = recv[e3 >> 10];
-                const int32_t q1 = k7_quantise<EXACT>(X[0][1], (double)(int)(e1 & 1023u) * r1[1] + r1[0], scale_f, pw.scale, undecided);
-                const int32_t q3 = k7_quantise<EXACT>(X[0][3], (double)(int)(e3 & 1023u) * r3[1] + r3[0], scale_f, pw.scale, undecided);
+                const int32_t q1 = k7_quantise<EXACT>(XL[0][1], (double)(int)(e1 & 1023u) * r1[1] + r1[0], scale_f, pw.scale, undecided);
+                const int32_t q3 = k7_quantise<EXACT>(XH[0][1], (double)(int)(e3 & 1023u) * r3[1] + r3[0], scale_f, pw.scale, undecided);
                 if (lane0) { code_store(row_of(NG - 1, 1), q1); code_store(row_of(NG - 1, 3), q3); }
             }
         };

@@ -60,16 +60,15 @@ def test_baseline_path_kernels_keep_their_registers():
             "k_p0_fwd_wave<1, 2, 32, true>", "k_p0_inv_wave<2, 32, true>",            # cfg 3 full frames (clip batch, in place)
             "k_p0_fwd_unit<double, PlanA9, 1, 2>", "k_p0_inv_unit<PlanA9, 32, 2>",   # cfg 2's 1024-sample tail
             "k_p0_fwd_half32<11, 4, 32>", "k_p0_inv_grp2<11, 2, 32, 2, false>",      # cfg 4
-            "k_p1_inv_wave<2>", "k_p1_ola<0>", "k_gol_decode_wave", "k_gol_encode"]   # cfg 5 (decode side, entropy stage)
+            "k_p1_fwd_wave<1, 2>", "k_p1_inv_wave<2>", "k_p1_ola<0>", "k_gol_decode_wave", "k_gol_encode"]   # cfg 5 (K7 since the end of round 3)
     for name in zero:
         hit = [k for k in rows if k.endswith(name) or name in k]
         assert hit, name
         for k in hit:
             assert rows[k] == 0, f"{k}: {rows[k]} B of scratch per lane"
-    # recorded debts: K7's coefficient registers through the quantiser
-    # (cfg 3's 896-sample tails: the mixed-radix kernels call the shared stage-in / pack helpers out of line -- 112 B of call frame,
-    #  no spilled registers)
-    debts = {"k_p1_fwd_wave<1, 2>": 256, "k_p0_fwd_mixed<1>": 112, "k_p0_inv_mixed<0>": 112}
+    # recorded debts: cfg 3's 896-sample tails -- the mixed-radix kernels call the shared stage-in / pack helpers
+    # out of line: 112 B of call frame, no spilled registers
+    debts = {"k_p0_fwd_mixed<1>": 112, "k_p0_inv_mixed<0>": 112}
     for name, cap in debts.items():
         hit = [k for k in rows if name in k]
         assert hit, name
