@@ -692,9 +692,17 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
     const v2u* pk2 = reinterpret_cast<const v2u*>(t.pk) + l;      // entry of (slot s, this lane): pk2[32 s]
     const float scale_f = (float)pw.scale;
     auto code_store = [&](unsigned char* p, int32_t v) { *reinterpret_cast<int32_t*>(p) = v; };
-    v2u ent[2];
-    auto ent_load = [&](int gi, int i) { ent[i & 1] = pk2[32 * job_slot(gi, i)]; };
-    ent_load(NG - 1, 0);
+    // The look-ups of a job -- its pk entry, then the {threshold, step} records of its four bins -- are two dependent LDS round
+    // trips; they run one job (records) and two jobs (entry) ahead of the arithmetic, across the groups.  Job j = 0 .. 15 is
+    // (group NG - 1 - j / JPG, place j % JPG).
+    auto slot_of_job = [&](int j) -> int { return job_slot(NG - 1 - j / JPG, j % JPG); };
+    v2u ent_cur = pk2[32 * slot_of_job(0)], ent_nxt = pk2[32 * slot_of_job(1)];
+    v2d rc_cur[4];
+    {
+        const uint32_t en0[4] = {ent_cur[0] & 0xffffu, ent_cur[0] >> 16, ent_cur[1] & 0xffffu, ent_cur[1] >> 16};
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) rc_cur[cq] = recv[en0[cq] >> 10];
+    }
     FRAD_FENCE();
 #pragma unroll
     for (int gi = NG - 1; gi >= 0; --gi) {
@@ -703,16 +711,28 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
         // EXACT = true (run only when some lane has one): every bin again with the exact fall-back, same stores
         auto group = [&](auto exact_tag) {
             constexpr bool EXACT = decltype(exact_tag)::value;
-            if constexpr (EXACT) ent_load(gi, 0);
 #pragma unroll
             for (int i = 0; i < JPG; ++i) {
-                const int s = job_slot(gi, i);
-                const v2u e2 = ent[i & 1];
-                const uint32_t en[4] = {e2[0] & 0xffffu, e2[0] >> 16, e2[1] & 0xffffu, e2[1] >> 16};
-                v2d rc[4];
+                const int s = job_slot(gi, i), j = (NG - 1 - gi) * JPG + i;
+                v2u e2; v2d rc[4];
+                v2u ent_nn = ent_nxt; v2d rc_nxt[4];
+                if constexpr (EXACT) {                            // the rare second run of a group fetches for itself
+                    e2 = pk2[32 * s];
+                    const uint32_t ex[4] = {e2[0] & 0xffffu, e2[0] >> 16, e2[1] & 0xffffu, e2[1] >> 16};
 #pragma unroll
-                for (int cq = 0; cq < 4; ++cq) rc[cq] = recv[en[cq] >> 10];
-                if (i + 1 < JPG) ent_load(gi, i + 1); else if (gi > 0 && !EXACT) ent_load(gi - 1, 0);
+                    for (int cq = 0; cq < 4; ++cq) rc[cq] = recv[ex[cq] >> 10];
+                } else {
+                    e2 = ent_cur;
+#pragma unroll
+                    for (int cq = 0; cq < 4; ++cq) rc[cq] = rc_cur[cq];
+                    if (j + 1 < 16) {                             // next job's records (its entry arrived a job ago), the entry after that
+                        const uint32_t en1[4] = {ent_nxt[0] & 0xffffu, ent_nxt[0] >> 16, ent_nxt[1] & 0xffffu, ent_nxt[1] >> 16};
+#pragma unroll
+                        for (int cq = 0; cq < 4; ++cq) rc_nxt[cq] = recv[en1[cq] >> 10];
+                        if (j + 2 < 16) ent_nn = pk2[32 * slot_of_job(j + 2)];
+                    }
+                }
+                const uint32_t en[4] = {e2[0] & 0xffffu, e2[0] >> 16, e2[1] & 0xffffu, e2[1] >> 16};
                 FRAD_FENCE();
                 int32_t qv[4];
 #pragma unroll
@@ -740,6 +760,13 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
                     code_store(pb, qv[1]);
                     code_store(pd, qv[3]);
                 }
+                if constexpr (!EXACT) {
+                    if (j + 1 < 16) {
+                        ent_cur = ent_nxt; ent_nxt = ent_nn;
+#pragma unroll
+                        for (int cq = 0; cq < 4; ++cq) rc_cur[cq] = rc_nxt[cq];
+                    }
+                }
                 FRAD_FENCE();
             }
             if (gi == NG - 1) {                                   // lane 0: bins 512 and 1536 (its slot-0 values of classes 1 and 3)
@@ -752,7 +779,7 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
             }
         };
         group(ic<0>{});
-        if (wave_any(undecided)) { group(ic<1>{}); if (gi > 0) ent_load(gi - 1, 0); }
+        if (wave_any(undecided)) group(ic<1>{});
         FRAD_FENCE();
         team_sync<64>();
         FRAD_FENCE();
