@@ -447,25 +447,25 @@ __device__ __forceinline__ int32_t k7_band_code(double t, const double* tqh) {
     else if (t >= tqh[n]) n += 1;
     return n;
 }
-// (int) round(sign(x) |x / div * scale|^0.75), the per-bin quantiser of profile1.py:27-36.  Decided in float32 wherever that is
+// (int) round(sign(x) |x / div|^0.75), x = X scale (the pair step's tables carry the scale): the per-bin quantiser of profile1.py:27-36.  Decided in float32 wherever that is
 // safe: the float32 value of |.|^0.75 carries a relative error below 1e-6 (two conversions, a reciprocal, two square roots,
 // three products), so unless it lies within 4e-6 y of a half-integer it rounds like the exact value.  The undecided bin (about
 // 1e-5 y of them) refines the float32 value by two Newton steps on y^4 div^3 = (|x| scale)^3 -- no division, no libm -- and,
 // should that still sit within 1e-12 of a half-integer h, compares (|x| scale)^3 with h^4 div^3 directly.
 template <bool EXACT>
-__device__ __forceinline__ int32_t k7_quantise(double x, double div, float scale, double scale_d, bool& undecided) {
+__device__ __forceinline__ int32_t k7_quantise(double x, double div, bool& undecided) {      // x = X 2^(bits-1) already
     const float xf = (float)x, df = (float)div;
-    const float mf = fabsf(xf) * k7_rcpf(df) * scale;
+    const float mf = fabsf(xf) * k7_rcpf(df);
     const float r = p1w_sqrtf(mf), yf = r * p1w_sqrtf(r);
-    const float fr = yf - floorf(yf);
-    int32_t qa = (int32_t)rintf(yf);
-    const bool und = !(fabsf(fr - 0.5f) > yf * 4e-6f + 1e-6f);   // (also NaN / Inf: div == 0, non-finite input)
+    const float ys = copysignf(yf, xf), rs = rintf(ys);       // the sign goes in before the rounding (round-half-even is symmetric)
+    int32_t qa = (int32_t)rs;
+    const bool und = !(fabsf(ys - rs) < 0.5f - (yf * 4e-6f + 1e-6f));      // (also NaN / Inf: div == 0, non-finite input)
     if constexpr (!EXACT) undecided |= und;
     else if (und) {
         if (div == 0.0 || x == 0.0 || x != x || div != div) qa = 0;              // x / inf -> 0; NaN -> 0 like the conversion
-        else if (!(mf < 1e30f)) qa = 0x7fffffff;              // beyond int32 (the exact conversion saturates as well)
+        else if (!(mf < 1e30f)) qa = xf < 0.0f ? -0x7fffffff : 0x7fffffff;       // beyond int32 (the exact conversion saturates as well)
         else {
-            const double a = fabs(x) * scale_d, a3 = a * a * a, d3 = div * div * div;
+            const double a = fabs(x), a3 = a * a * a, d3 = div * div * div;
             double y = (double)yf;
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
@@ -476,9 +476,10 @@ __device__ __forceinline__ int32_t k7_quantise(double x, double div, float scale
             const double up = fabs(y - hh) > y * 1e-12 ? (y > hh ? 1.0 : 0.0) : (a3 > (hh * hh) * (hh * hh) * d3 ? 1.0 : 0.0);
             const double qd = n + up;
             qa = qd < 2147483647.0 ? (int32_t)qd : 0x7fffffff;
+            qa = xf < 0.0f ? -qa : qa;
         }
     }
-    return xf < 0.0f ? -qa : qa;
+    return qa;
 }
 // pk[(s * 32 + l) * 4 + cls] = (band j of the bin that lane l holds for job slot s, class cls) << 10 | position of the bin inside
 // band j; classes: X[k], X[M - k], X[M + k], X[N - k], k = wave_job_k(l, s) (lane 0 of slot 0: bins 0, 512, 1024, 1536).  One 8-byte
@@ -662,7 +663,6 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
             energy += (2 * i < cnt) ? v[0] : 0.0;
             energy += (2 * i + 1 < cnt) ? v[1] : 0.0;
         }
-        energy *= pw.scale * pw.scale;                            // sum((X scale)^2): the scale is a power of two
         double th = 0.0;
         if (b < pw.nb_used) {                                     // p1tools.py:30-31
             const double sfq = k7_pow04(energy / (double)bins), fl = t.floor_[b];
@@ -690,7 +690,6 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
     auto job_slot = [](int gi, int i) -> int { const int tt = gi * (JPG / 2) + (i >> 1); return (i & 1) ? 15 - tt : tt; };
     const v2d* recv = reinterpret_cast<const v2d*>(rec);
     const v2u* pk2 = reinterpret_cast<const v2u*>(t.pk) + l;      // entry of (slot s, this lane): pk2[32 s]
-    const float scale_f = (float)pw.scale;
     auto code_store = [&](unsigned char* p, int32_t v) { *reinterpret_cast<int32_t*>(p) = v; };
     // The look-ups of a job -- its pk entry, then the {threshold, step} records of its four bins -- are two dependent LDS round
     // trips; they run one job (records) and two jobs (entry) ahead of the arithmetic, across the groups.  Job j = 0 .. 15 is
@@ -738,7 +737,7 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
 #pragma unroll
                 for (int cq = 0; cq < 4; ++cq) {                  // np.linspace without its end point: t0 + i * step (two roundings)
                     const double y = (double)(int)(en[cq] & 1023u) * rc[cq][1];
-                    qv[cq] = k7_quantise<EXACT>(cq < 2 ? XL[s][cq] : XH[s][cq - 2], y + rc[cq][0], scale_f, pw.scale, undecided);
+                    qv[cq] = k7_quantise<EXACT>(cq < 2 ? XL[s][cq] : XH[s][cq - 2], y + rc[cq][0], undecided);
                 }
                 const int tt = s < 8 ? s : 15 - s, tl = tt - gi * (JPG / 2);
                 const int offa = 64 * tl * ES + (s < 8 ? la : lb);
@@ -773,8 +772,8 @@ __device__ __forceinline__ void wave_p1_tail(cx<T> (&E)[16], cx<T> (&O)[16], con
                 const v2u e2 = pk2[0];
                 const uint32_t e1 = e2[0] >> 16, e3 = e2[1] >> 16;
                 const v2d r1 = recv[e1 >> 10], r3 = recv[e3 >> 10];
-                const int32_t q1 = k7_quantise<EXACT>(XL[0][1], (double)(int)(e1 & 1023u) * r1[1] + r1[0], scale_f, pw.scale, undecided);
-                const int32_t q3 = k7_quantise<EXACT>(XH[0][1], (double)(int)(e3 & 1023u) * r3[1] + r3[0], scale_f, pw.scale, undecided);
+                const int32_t q1 = k7_quantise<EXACT>(XL[0][1], (double)(int)(e1 & 1023u) * r1[1] + r1[0], undecided);
+                const int32_t q3 = k7_quantise<EXACT>(XH[0][1], (double)(int)(e3 & 1023u) * r3[1] + r3[0], undecided);
                 if (lane0) { code_store(row_of(NG - 1, 1), q1); code_store(row_of(NG - 1, 3), q3); }
             }
         };
@@ -832,7 +831,9 @@ wave_fwd_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__
     constexpr int ES = CC * NB;                        // payload bytes per bin
     FRAD_DYN_SMEM(smem);
     const T deferred = (T)pcm_deferred_scale(g.dtype, g.raw_be);
-    const T sc = ((T)1 / (T)(2 * N)) * deferred;             // exact power of two
+    T sc = ((T)1 / (T)(2 * N)) * deferred;                   // exact power of two
+    if constexpr (MODE == 1) sc *= (T)pw.scale;               // profile 1: the coefficients leave the pair step as X 2^(bits-1) (profile1.py:26-27:
+                                                              //  every later use has that factor; a power of two commutes with the roundings)
     {
         cx<T>* l = reinterpret_cast<cx<T>*>(smem);
         for (int i = threadIdx.x; i < WaveLayout::SLOTS; i += blockDim.x) {
