@@ -12,7 +12,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_trace -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof_${TAG}_trace.log 2>&1 || exit 1
-tail -1 $R/gpurun_out/prof_${TAG}_trace.log > $R/gpurun_out/prof_${TAG}_bench_line.json
+grep "^{\"metric\"" $R/gpurun_out/prof_${TAG}_trace.log | tail -1 > $R/gpurun_out/prof_${TAG}_bench_line.json   # (rocprofv3 prints its own closing lines after the program's)
 echo "trace done"
 cd $R
 bash tools/pmc_any.sh ${TAG}_bench bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_${TAG}_bench.log 2>&1 || { tail -3 $R/gpurun_out/pmc_${TAG}_bench.log; exit 1; }
