@@ -284,9 +284,12 @@ int frad_p4_analogue(const void* pcm, int32_t pcm_dtype, int64_t n_frames, int32
     const long long NC = (long long)N * C;
     const int U = unit_values(bits);
     const bool fast = NC >= U && aligned16(pcm) && ((frame_stride * C) << lg) % 16 == 0 && aligned16(payload) && payload_stride % 16 == 0;
-    const int bpf = blocks_per_frame(fast ? (NC / U + 3) / 4 : NC);          // fast path: four units per thread
+    int bpf = blocks_per_frame(fast ? (NC / U + 3) / 4 : NC);                // fast path: four units per thread
     if (n_frames * bpf > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
     dim3 grid((unsigned)(n_frames * bpf));
+    // small frames (fewer than four units per thread of one block): a wave per frame, four frames per block (bpf = 0)
+    static const bool no_wave = tune("FRAD_TUNE_NO_P4_WAVE") != nullptr;
+    if (fast && !no_wave && NC / U < 1024) { bpf = 0; grid = dim3((unsigned)((n_frames + 3) / 4)); }
     const unsigned char* in = static_cast<const unsigned char*>(pcm);
     unsigned char* out = static_cast<unsigned char*>(payload);
     if (fast) {

@@ -104,8 +104,15 @@ __device__ __forceinline__ void p4_pack_body(const unsigned char* __restrict__ p
                                              double* absmax, const Geom& g, int bpf) {
     constexpr int U = unit_values(BITS), UB = unit_bytes(BITS);
     constexpr int RAWB = U << LG, NW = RAWB >= 4 ? RAWB / 4 : 1;
-    const long long f = blockIdx.x / bpf;
-    const int chunk = blockIdx.x - (int)(f * bpf);
+    // bpf > 0: a frame is shared by bpf blocks.  bpf == 0 (frames of fewer than 4 units per thread of a block: the stereo
+    // N = 2048 frames of the BASELINE configurations are 512 units at 16 bit): ONE WAVE per frame, so that a lane still has
+    // four loads in flight; a block of 256 threads then takes four frames.
+    long long f; int chunk, tid, tsz;
+    if (bpf > 0) { f = blockIdx.x / bpf; chunk = blockIdx.x - (int)(f * bpf); tid = threadIdx.x; tsz = blockDim.x; }
+    else {
+        f = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); chunk = 0; tid = threadIdx.x & 63; tsz = 64;
+        if (f >= g.n_frames) return;                         // (whole waves leave; the kernel has no block barrier)
+    }
     const long long NC = (long long)g.N * g.C;
     const long long units = NC / U;
     const unsigned char* src = pcm + ((f * g.frame_stride * g.C) << LG);
@@ -134,8 +141,8 @@ __device__ __forceinline__ void p4_pack_body(const unsigned char* __restrict__ p
             pack_unit<BITS>(codes, le, out);
             store_words<UB / 4, BITS == 32>(dst + u * UB, out);
         };
-        const long long step = (long long)bpf * blockDim.x;
-        long long u = (long long)chunk * blockDim.x + threadIdx.x;
+        const long long step = bpf > 0 ? (long long)bpf * tsz : tsz;
+        long long u = (long long)chunk * tsz + tid;
         for (; u + 3 * step < units; u += 4 * step) {
             uint32_t w[4][NW];
 #pragma unroll
@@ -143,10 +150,12 @@ __device__ __forceinline__ void p4_pack_body(const unsigned char* __restrict__ p
 #pragma unroll
             for (int b = 0; b < 4; ++b) emit(u + b * step, w[b]);
         }
-        for (; u < units; u += step) {
-            uint32_t w[NW];
-            load(u, w);
-            emit(u, w);
+        if (u < units) {                                     // the last one to three units of this thread, loaded together as well
+            uint32_t w[3][NW];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) if (u + b * step < units) load(u + b * step, w[b]);
+#pragma unroll
+            for (int b = 0; b < 3; ++b) if (u + b * step < units) emit(u + b * step, w[b]);
         }
     });
     const int tail = (int)(NC - units * U);
@@ -155,9 +164,9 @@ __device__ __forceinline__ void p4_pack_body(const unsigned char* __restrict__ p
         auto value = [&](long long i) { return cvt_pcm<T>(load_raw(src + (i << LG), LG), g.dtype, g.raw_be); };
         auto code_of = [&](long long i) -> u64 { return i < NC ? storage_code<T>(value(i), BITS) : 0; };
         const long long b0 = units * UB, b1 = (BITS == 12) ? (NC * 3 + 1) / 2 : NC * (BITS / 8);
-        for (long long s = b0 + threadIdx.x; s < b1; s += blockDim.x)
+        for (long long s = b0 + tid; s < b1; s += tsz)
             dst[s] = (unsigned char)payload_byte(s, BITS, le, NC, code_of);
-        for (long long i = first + threadIdx.x; i < NC; i += blockDim.x) {
+        for (long long i = first + tid; i < NC; i += tsz) {
             const u64 a = abs_bits((double)value(i));
             mx = a > mx ? a : mx;
         }
