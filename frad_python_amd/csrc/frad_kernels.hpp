@@ -101,7 +101,7 @@ __device__ __forceinline__ void block_absmax_commit(u64 mx, double* absmax, long
 // =============================================================================================
 template <typename T, int BITS, int LG>
 __device__ __forceinline__ void p4_pack_body(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload,
-                                             double* absmax, const Geom& g, int bpf) {
+                                             double* absmax, const Geom& g, int bpf, v4u* stage) {
     constexpr int U = unit_values(BITS), UB = unit_bytes(BITS);
     constexpr int RAWB = U << LG, NW = RAWB >= 4 ? RAWB / 4 : 1;
     // bpf > 0: a frame is shared by bpf blocks.  bpf == 0 (frames of fewer than 4 units per thread of a block: the stereo
@@ -128,34 +128,62 @@ __device__ __forceinline__ void p4_pack_body(const unsigned char* __restrict__ p
             if constexpr (RAWB >= 4) load_words<NW>(src + u * RAWB, w);
             else w[0] = *FRAD_GCPTR(unsigned short, src + u * RAWB);
         };
-        auto emit = [&](long long u, const uint32_t (&w)[NW]) {
-            u64 codes[U];
-#pragma unroll
-            for (int i = 0; i < U; ++i) {
-                const T v = cvt_pcm_c<T, CODE, RAW>(word_elem<LG>(w, i));
-                const u64 a = abs_bits((double)v);
-                mx = a > mx ? a : mx;
-                codes[i] = storage_code<T>(v, BITS);
-            }
+        const int lane = threadIdx.x & 63;
+        auto emit = [&](long long u, const uint32_t (&w)[NW], bool valid) {      // called by whole waves (`valid`: this lane has a unit)
             uint32_t out[UB / 4];
-            pack_unit<BITS>(codes, le, out);
-            store_words<UB / 4, BITS == 32>(dst + u * UB, out);
+            if (valid) {
+                u64 codes[U];
+#pragma unroll
+                for (int i = 0; i < U; ++i) {
+                    const T v = cvt_pcm_c<T, CODE, RAW>(word_elem<LG>(w, i));
+                    const u64 a = abs_bits((double)v);
+                    mx = a > mx ? a : mx;
+                    codes[i] = storage_code<T>(v, BITS);
+                }
+                pack_unit<BITS>(codes, le, out);
+            }
+#ifndef FRAD_HOST_EMULATION
+            if constexpr (UB == 48) {
+                // 48-byte units: a lane's three 16-byte pieces lie 48 bytes apart in the payload, 64 places per store
+                // instruction.  A wave that holds 64 consecutive units passes the pieces through LDS (piece 3 lane + k in,
+                // piece 64 k + lane out; 12- and 4-bank strides: conflict-free) and stores three whole 1 KiB rows.
+                const long long u0 = u - lane;                // the wave's first unit (the same in every lane)
+                if (stage != nullptr && u0 + 64 <= units) {
+                    v4u* st = stage + (threadIdx.x >> 6) * 192;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) st[3 * lane + k] = v4u{out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]};
+                    team_sync<64>();
+                    v4u row[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) row[k] = st[64 * k + lane];
+                    team_sync<64>();
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) FRAD_NT_STORE(row[k], FRAD_GPTR(v4u, dst + u0 * UB) + 64 * k + lane);
+                    return;
+                }
+            }
+#endif
+            if (valid) store_words<UB / 4, BITS == 32>(dst + u * UB, out);
         };
         const long long step = bpf > 0 ? (long long)bpf * tsz : tsz;
         long long u = (long long)chunk * tsz + tid;
-        for (; u + 3 * step < units; u += 4 * step) {
-            uint32_t w[4][NW];
+        // loop conditions on the wave's LAST lane (u - lane + 63), so that a wave stays together.  NBAT units of a thread are
+        // loaded before the first is converted: at least 64 raw bytes in flight per lane, but no more units than that takes
+        // (four 64-byte units at 12 bit cost the kernel its occupancy: 332 VGPRs)
+        constexpr int NBAT = RAWB >= 64 ? 1 : RAWB >= 32 ? 2 : 4;
+        for (; u - lane + 63 + (NBAT - 1) * step < units; u += NBAT * step) {
+            uint32_t w[NBAT][NW];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) load(u + b * step, w[b]);
+            for (int b = 0; b < NBAT; ++b) load(u + b * step, w[b]);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) emit(u + b * step, w[b]);
+            for (int b = 0; b < NBAT; ++b) emit(u + b * step, w[b], true);
         }
-        if (u < units) {                                     // the last one to three units of this thread, loaded together as well
-            uint32_t w[3][NW];
+        for (; u - lane < units; u += NBAT * step) {         // what is left (ragged waves), loaded together as well
+            uint32_t w[NBAT][NW];
 #pragma unroll
-            for (int b = 0; b < 3; ++b) if (u + b * step < units) load(u + b * step, w[b]);
+            for (int b = 0; b < NBAT; ++b) if (u + b * step < units) load(u + b * step, w[b]);
 #pragma unroll
-            for (int b = 0; b < 3; ++b) if (u + b * step < units) emit(u + b * step, w[b]);
+            for (int b = 0; b < NBAT; ++b) if (u - lane + b * step < units) emit(u + b * step, w[b], u + b * step < units);
         }
     });
     const int tail = (int)(NC - units * U);
@@ -177,8 +205,15 @@ __device__ __forceinline__ void p4_pack_body(const unsigned char* __restrict__ p
 template <int BITS, int LG>
 __global__ void __launch_bounds__(256) k_p4_pack(const unsigned char* __restrict__ pcm, unsigned char* __restrict__ payload,
                                                  double* absmax, Geom g, int bpf) {
-    if (dtype_is_f32_class(g.dtype)) p4_pack_body<float, BITS, LG>(pcm, payload, absmax, g, bpf);
-    else p4_pack_body<double, BITS, LG>(pcm, payload, absmax, g, bpf);
+    v4u* stage = nullptr;
+#ifndef FRAD_HOST_EMULATION
+    if constexpr (unit_bytes(BITS) == 48) {                  // 3 KiB per wave: the 48-byte units' pieces change lanes here
+        __shared__ v4u p4_stage[4 * 192];
+        stage = p4_stage;
+    }
+#endif
+    if (dtype_is_f32_class(g.dtype)) p4_pack_body<float, BITS, LG>(pcm, payload, absmax, g, bpf, stage);
+    else p4_pack_body<double, BITS, LG>(pcm, payload, absmax, g, bpf, stage);
 }
 
 // Any alignment / any geometry: one thread per payload byte and per value.
@@ -278,6 +313,50 @@ __global__ void __launch_bounds__(256) k_p4_unpack_pairs(const unsigned char* __
     }
     if (chunk == 0 && threadIdx.x == 0 && (NC & 1))
         dst[NC - 1] = code_to_f64(code_from_bytes(src, NC - 1, BITS, le), BITS);
+}
+
+// 12-bit depth: one thread = 3 payload bytes = two values = one 16-byte output row (the 48-byte unit kernel leaves a lane's
+// sixteen stores 256 bytes apart: 64 places per store instruction).  The three bytes come out of the aligned word that holds
+// the first of them and, when they straddle it, the next one (rows are 16-byte aligned and strided, so an aligned word that
+// holds a payload byte lies inside the row's stride); four pairs are loaded before the first is converted.
+template <int UNUSED>
+__global__ void __launch_bounds__(256) k_p4_unpack_3b(const unsigned char* __restrict__ payload, double* __restrict__ out,
+                                                      Geom g, int bpf) {
+    const long long f = blockIdx.x / bpf;
+    const int chunk = blockIdx.x - (int)(f * bpf);
+    const long long NC = (long long)g.N * g.C, pairs = NC / 2;
+    const unsigned char* src = payload + f * g.payload_stride;
+    double* dst = out + f * NC;
+    auto load = [&](long long p, uint32_t (&w)[2]) {
+        const long long o = 3 * p;
+        const unsigned char* a = src + (o & ~3LL);
+        w[0] = *FRAD_GCPTR(uint32_t, a);
+        w[1] = (o & 3) >= 2 ? *FRAD_GCPTR(uint32_t, a + 4) : 0u;
+    };
+    auto emit = [&](long long p, const uint32_t (&w)[2]) {
+        const int sh = 8 * (int)((3 * p) & 3);
+        const uint32_t t = (uint32_t)((((u64)w[1] << 32) | w[0]) >> sh);      // payload bytes 3p, 3p + 1, 3p + 2 in the low 24 bits
+        const uint32_t b0 = t & 0xffu, b1 = (t >> 8) & 0xffu, b2 = (t >> 16) & 0xffu;
+        const u64 c0 = (b0 << 4) | (b1 >> 4), c1 = ((b1 & 0xfu) << 8) | b2;
+        v2d v = {code_to_f64(c0, 12), code_to_f64(c1, 12)};
+        FRAD_NT_STORE(v, FRAD_GPTR(v2d, dst) + p);
+    };
+    const long long step = (long long)bpf * blockDim.x;
+    long long p = (long long)chunk * blockDim.x + threadIdx.x;
+    for (; p + 3 * step < pairs; p += 4 * step) {
+        uint32_t w[4][2];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) load(p + b * step, w[b]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) emit(p + b * step, w[b]);
+    }
+    for (; p < pairs; p += step) {
+        uint32_t w[2];
+        load(p, w);
+        emit(p, w);
+    }
+    if (chunk == 0 && threadIdx.x == 0 && (NC & 1))
+        dst[NC - 1] = code_to_f64(code_from_bytes(src, NC - 1, 12, false), 12);
 }
 
 // 24 / 48-bit depths: one thread = 12 payload bytes = 4 / 2 values, i.e. 32 / 16 contiguous output bytes per lane
