@@ -68,7 +68,11 @@ def check_p0_payload(got, want, bits, le, fmt, N):
 @pytest.mark.parametrize("fmt", ["s16le", "f64le", "f32le", "u8", "s32be", "f16le", "s64le", "u16be", "f64be", "s8"])
 def test_p4_bit_exact_all_depths(be, fmt):
     rng = np.random.default_rng(11)
-    for (N, C, F) in _sizes(be, [(2048, 2, 2), (5, 1, 3), (33, 3, 2)], [(2048, 2, 5), (5, 1, 3), (33, 3, 2), (4096, 8, 2), (1, 1, 1)]):
+    # (1608, 1) / (804, 2): 16-byte aligned rows whose units fill one wave and part of the next at 24 bit (100 units + 8 values),
+    # three waves and a bit at 48 bit, half a wave at 12 bit: whole-row (LDS transpose) and direct stores of K1 in one frame,
+    # the 3-byte pairs of the 12-bit K2; (16392, 2): the same with a block-shared frame (more than 1024 units)
+    for (N, C, F) in _sizes(be, [(2048, 2, 2), (5, 1, 3), (33, 3, 2)],
+                            [(2048, 2, 5), (5, 1, 3), (33, 3, 2), (4096, 8, 2), (1, 1, 1), (1608, 1, 5), (804, 2, 3), (16392, 2, 2)]):
         raw = synth.to_pcm(rng.uniform(-1, 1, (F * N, C)), fmt)
         for bits in fo.DEPTHS:
             for le in (False, True):
