@@ -319,16 +319,20 @@ int frad_p4_digital(const void* payload, int64_t payload_stride, int64_t n_frame
     const long long NC = (long long)N * C;
     const int U = unit_values(bits);
     const bool fast = NC >= U && aligned16(payload) && payload_stride % 16 == 0 && aligned16(pcm_out) && (NC % 2 == 0);
-    // 16 bit: a pair of values per thread keeps the float64 stores contiguous (4.0 -> 5.5 TB/s); at 32 bit the unit
-    // kernel is already at 5.7 TB/s and measured faster (`fast`: NC even, aligned rows)
-    const bool pairs = fast && (bits == 16 || bits == 12) && !tune("FRAD_TUNE_NO_P4_PAIRS");   // (12 bit: three payload bytes per pair)
-    const bool sub12 = fast && (bits == 24 || bits == 48) && !tune("FRAD_TUNE_NO_P4_PAIRS");   // same idea, 12-byte sub-units
+    // a pair of values per thread keeps the float64 stores contiguous: whole 1 KiB rows per store instruction, nontemporal
+    // (16 bit 4.0 -> 7.1 TB/s; 12 / 24 / 32 bit 2.8 / 5.5 / 5.9 -> 7.0 TB/s in round 3; `fast`: NC even, aligned rows)
+    static const bool pairs24 = tune("FRAD_TUNE_NO_P4_PAIRS24") == nullptr;
+    static const bool pairs32 = tune("FRAD_TUNE_NO_P4_PAIRS32") == nullptr;
+    const bool pairs = fast && (bits == 16 || bits == 12 || (bits == 24 && pairs24) || (bits == 32 && pairs32)) && !tune("FRAD_TUNE_NO_P4_PAIRS");   // (12 / 24 bit: 3 / 6 payload bytes per pair)
+    const bool sub12 = fast && !pairs && (bits == 24 || bits == 48) && !tune("FRAD_TUNE_NO_P4_PAIRS");   // same idea, 12-byte sub-units
     const int bpf = blocks_per_frame(pairs ? (NC / 2 + 3) / 4 : sub12 ? (NC / (96 / bits) + 3) / 4 : fast ? NC / U : NC);
     if (n_frames * bpf > 0x7fffffffLL) return FRAD_E_UNSUPPORTED;
     dim3 grid((unsigned)(n_frames * bpf));
     const unsigned char* in = static_cast<const unsigned char*>(payload);
     if (pairs) {
-        if (bits == 12) hipLaunchKernelGGL(k_p4_unpack_3b<0>, grid, dim3(256), 0, s, in, pcm_out, g, bpf);
+        if (bits == 12) hipLaunchKernelGGL(k_p4_unpack_3b<12>, grid, dim3(256), 0, s, in, pcm_out, g, bpf);
+        else if (bits == 24) hipLaunchKernelGGL(k_p4_unpack_3b<24>, grid, dim3(256), 0, s, in, pcm_out, g, bpf);
+        else if (bits == 32) hipLaunchKernelGGL(k_p4_unpack_pairs<32>, grid, dim3(256), 0, s, in, pcm_out, g, bpf);
         else hipLaunchKernelGGL(k_p4_unpack_pairs<16>, grid, dim3(256), 0, s, in, pcm_out, g, bpf);
     } else if (sub12) {
         if (bits == 24) hipLaunchKernelGGL(k_p4_unpack_12b<24>, grid, dim3(256), 0, s, in, pcm_out, g, bpf);

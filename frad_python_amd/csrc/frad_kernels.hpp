@@ -268,7 +268,8 @@ __global__ void __launch_bounds__(256) k_p4_unpack(const unsigned char* __restri
 #pragma unroll
         for (int i = 0; i < U / 2; ++i) {
             v2d v = {code_to_f64(codes[2 * i], BITS), code_to_f64(codes[2 * i + 1], BITS)};
-            *(FRAD_GPTR(v2d, dst + u * U) + i) = v;
+            if constexpr (U == 2) FRAD_NT_STORE(v, FRAD_GPTR(v2d, dst + u * U) + i);      // (64 bit: a wave's store is one contiguous 1 KiB row)
+            else *(FRAD_GPTR(v2d, dst + u * U) + i) = v;
         }
     }
     if (chunk == 0)
@@ -315,30 +316,40 @@ __global__ void __launch_bounds__(256) k_p4_unpack_pairs(const unsigned char* __
         dst[NC - 1] = code_to_f64(code_from_bytes(src, NC - 1, BITS, le), BITS);
 }
 
-// 12-bit depth: one thread = 3 payload bytes = two values = one 16-byte output row (the 48-byte unit kernel leaves a lane's
-// sixteen stores 256 bytes apart: 64 places per store instruction).  The three bytes come out of the aligned word that holds
-// the first of them and, when they straddle it, the next one (rows are 16-byte aligned and strided, so an aligned word that
-// holds a payload byte lies inside the row's stride); four pairs are loaded before the first is converted.
-template <int UNUSED>
+// 12- and 24-bit depths: one thread = 3 / 6 payload bytes = two values = one 16-byte output row, so that a wave's store instruction
+// writes 1 KiB of contiguous float64 (the 48-byte unit kernel leaves a lane's sixteen stores 256 bytes apart at 12 bit, the
+// 12-byte kernel below two stores 32 bytes apart at 24 bit).  The bytes come out of the aligned word that holds the first of
+// them and, when they reach beyond it, the next one (rows are 16-byte aligned and strided, so an aligned word that holds a
+// payload byte lies inside the row's stride); four pairs are loaded before the first is converted.
+template <int BITS>
 __global__ void __launch_bounds__(256) k_p4_unpack_3b(const unsigned char* __restrict__ payload, double* __restrict__ out,
                                                       Geom g, int bpf) {
+    static_assert(BITS == 12 || BITS == 24, "3 or 6 bytes per pair");
+    constexpr int PB = BITS / 4;                              // payload bytes per pair
     const long long f = blockIdx.x / bpf;
     const int chunk = blockIdx.x - (int)(f * bpf);
     const long long NC = (long long)g.N * g.C, pairs = NC / 2;
     const unsigned char* src = payload + f * g.payload_stride;
     double* dst = out + f * NC;
+    const bool le = g.le != 0;
     auto load = [&](long long p, uint32_t (&w)[2]) {
-        const long long o = 3 * p;
+        const long long o = PB * p;
         const unsigned char* a = src + (o & ~3LL);
         w[0] = *FRAD_GCPTR(uint32_t, a);
-        w[1] = (o & 3) >= 2 ? *FRAD_GCPTR(uint32_t, a + 4) : 0u;
+        w[1] = (BITS == 24 || (o & 3) >= 2) ? *FRAD_GCPTR(uint32_t, a + 4) : 0u;
     };
     auto emit = [&](long long p, const uint32_t (&w)[2]) {
-        const int sh = 8 * (int)((3 * p) & 3);
-        const uint32_t t = (uint32_t)((((u64)w[1] << 32) | w[0]) >> sh);      // payload bytes 3p, 3p + 1, 3p + 2 in the low 24 bits
-        const uint32_t b0 = t & 0xffu, b1 = (t >> 8) & 0xffu, b2 = (t >> 16) & 0xffu;
-        const u64 c0 = (b0 << 4) | (b1 >> 4), c1 = ((b1 & 0xfu) << 8) | b2;
-        v2d v = {code_to_f64(c0, 12), code_to_f64(c1, 12)};
+        const int sh = 8 * (int)((PB * p) & 3);
+        const u64 t = (((u64)w[1] << 32) | w[0]) >> sh;       // the pair's payload bytes, first byte lowest
+        u64 c0, c1;
+        if constexpr (BITS == 12) {
+            const uint32_t b0 = (uint32_t)t & 0xffu, b1 = ((uint32_t)t >> 8) & 0xffu, b2 = ((uint32_t)t >> 16) & 0xffu;
+            c0 = (b0 << 4) | (b1 >> 4); c1 = ((b1 & 0xfu) << 8) | b2;
+        } else {
+            const uint32_t lo = (uint32_t)t & 0xffffffu, hi = (uint32_t)(t >> 24) & 0xffffffu;
+            c0 = le ? lo : bswap32(lo) >> 8; c1 = le ? hi : bswap32(hi) >> 8;
+        }
+        v2d v = {code_to_f64(c0, BITS), code_to_f64(c1, BITS)};
         FRAD_NT_STORE(v, FRAD_GPTR(v2d, dst) + p);
     };
     const long long step = (long long)bpf * blockDim.x;
@@ -356,7 +367,7 @@ __global__ void __launch_bounds__(256) k_p4_unpack_3b(const unsigned char* __res
         emit(p, w);
     }
     if (chunk == 0 && threadIdx.x == 0 && (NC & 1))
-        dst[NC - 1] = code_to_f64(code_from_bytes(src, NC - 1, 12, false), 12);
+        dst[NC - 1] = code_to_f64(code_from_bytes(src, NC - 1, BITS, le), BITS);
 }
 
 // 24 / 48-bit depths: one thread = 12 payload bytes = 4 / 2 values, i.e. 32 / 16 contiguous output bytes per lane
@@ -386,7 +397,11 @@ __global__ void __launch_bounds__(256) k_p4_unpack_12b(const unsigned char* __re
             val[i] = code_to_f64(c, BITS);
         }
 #pragma unroll
-        for (int i = 0; i < V / 2; ++i) { v2d v = {val[2 * i], val[2 * i + 1]}; *(FRAD_GPTR(v2d, dst + u * V) + i) = v; }
+        for (int i = 0; i < V / 2; ++i) {
+            v2d v = {val[2 * i], val[2 * i + 1]};
+            if constexpr (V == 2) FRAD_NT_STORE(v, FRAD_GPTR(v2d, dst + u * V) + i);      // (48 bit: contiguous rows)
+            else *(FRAD_GPTR(v2d, dst + u * V) + i) = v;
+        }
     };
     const long long step = (long long)bpf * blockDim.x;
     long long u = (long long)chunk * blockDim.x + threadIdx.x;
