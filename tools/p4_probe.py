@@ -3,6 +3,8 @@ samples), every storage depth, s16le and f32le PCM.  FRAD_TUNE_NO_P4_WAVE=1 sele
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import frad_python_amd._lib as _L
+if os.environ.get('KB_LIB'): _L.LIB_PATH = os.path.join(os.path.dirname(_L.LIB_PATH), os.environ['KB_LIB'])      # diagnostic builds
 from frad_python_amd import core
 dev = torch.device("cuda:0")
 F, N, C = 14062, 2048, 2
