@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A few launches of every kernel OFF the headline path, for the PMC passes of tools/profile_round.sh (rocprofv3 --pmc):
 K7 / K8 on the 10-minute cfg-5 clip, the Exp-Golomb coder / decoder on the same frames, cfg 4 encode / decode (2 812 frames of
-192 kHz 7.1 float32, N = 4096), cfg 3's 896-sample tail frames of 512 clips in place (mixed-radix kernels), the overlap-add."""
+192 kHz 7.1 float32, N = 4096), cfg 3's 896-sample tail frames of 512 clips in place (mixed-radix kernels), the overlap-add,
+profile-4 pack / unpack at 12 / 16 / 24 bit."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,5 +38,14 @@ whole = torch.empty((512, 48000, 2), dtype=torch.float64, device=dev)
 for _ in range(REPS):
     et = core.analogue_clips(clips, "s16le", 896, 32, first=23 * 2048)
     core.digital_clips(et.payload, whole, 896, 32, first=23 * 2048)
+torch.cuda.synchronize()
+del clips, whole, et
+# profile 4 (K1 / K2) at cfg 2's size: 16-bit (wave per frame), 24-bit (48-byte units through LDS, 6-byte pairs), 12-bit (3-byte pairs)
+F2, N2, C2 = 14062, 2048, 2
+p2 = (torch.randn((F2 * N2, C2), generator=g, device=dev) * 8000).clamp(-32768, 32767).to(torch.int16)
+for _ in range(REPS):
+    for bits in (16, 24, 12):
+        e4 = core.analogue_batch(4, p2, "s16le", F2, N2, C2, bits, check_overflow=False)
+        d2 = core.digital_batch(4, e4.payload, F2, N2, C2, bits)
 torch.cuda.synchronize()
 print("ok")
